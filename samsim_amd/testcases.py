@@ -1,0 +1,129 @@
+"""Host-side mirror of the reference's per-testcase setup `init(testcase)` (mo_init.f90:73-2034) for the
+testcases in scope (1 and 4) plus the synthetic BASELINE configurations.
+
+`init` in the reference fills the `mo_data` globals; here it returns the POD `Config` that crosses the C-ABI
+and the SoA initial `State`.  Defaults follow mo_init.f90:83-132, the common tail mo_init.f90:1981-2031.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .capi import Config, State, S, A, NSCAL, NPROG, NARR
+
+RHO_L = 1028.0      # mo_parameters.f90:53
+C_L = 3400.0        # mo_parameters.f90:51
+RHO_SNOW = 330.0    # mo_parameters.f90:87
+LATENT_HEAT = 333500.0
+LENGTH_INPUT = 13148  # mo_grotz.f90:132
+
+
+def default_config() -> Config:
+    """default flags, mo_init.f90:83-109, and mo_parameters.f90:107,110"""
+    c = Config()
+    c.struct_size = __import__("ctypes").sizeof(Config)
+    c.boundflux_flag, c.atmoflux_flag, c.albedo_flag = 1, 1, 2
+    c.grav_heat_flag, c.flush_heat_flag, c.flood_flag, c.flush_flag, c.grav_flag, c.harmonic_flag = 1, 1, 2, 5, 2, 2
+    c.prescribe_flag, c.salt_flag = 1, 1
+    c.turb_flag, c.bottom_flag, c.tank_flag = 2, 1, 1
+    c.precip_flag, c.freeboard_snow_flag, c.snow_flush_flag, c.snow_precip_flag = 0, 0, 1, 1
+    c.debug_flag, c.bgc_flag, c.lab_snow_flag = 1, 1, 0
+    c.k_snow_flush, c.max_flux_plate = 0.75, 10000.0
+    return c
+
+
+def _finish(c: Config) -> Config:
+    """common tail, mo_init.f90:1994-2001"""
+    c.n_middle = c.nlayer - c.n_top - c.n_bottom
+    c.thick_min = c.thick_0 / 2.0
+    c.i_time_out = int(c.time_out / c.dt)
+    return c
+
+
+def i_time(c: Config) -> int:
+    return int(c.time_total / c.dt)
+
+
+def _blank_state(c: Config, ncol: int) -> State:
+    """sub_allocate zeros (mo_init.f90:2081-2087) + defaults mo_init.f90:1982-1990"""
+    st = State.empty(ncol, c.nlayer, NARR)
+    st.arr("T")[:] = c.T_bottom
+    st.arr("S_bu")[:] = c.S_bu_bottom
+    st.arr("psi_l")[:] = 1.0
+    st.sc("precip_scale")[:] = 1.0
+    return st
+
+
+def testcase1(ncol: int = 1):
+    """mo_init.f90:865-945: cooling-plate tank experiment, T_top toggles -5/-10 every 12 h (bgc off)."""
+    c = default_config()
+    c.testcase = 1
+    c.nlayer, c.n_top, c.n_bottom = 90, 5, 5
+    c.turb_flag, c.boundflux_flag, c.grav_heat_flag, c.flush_flag, c.salt_flag = 1, 1, 1, 1, 2
+    c.T_bottom, c.S_bu_bottom = -1.0, 34.0
+    c.thick_0, c.dt, c.time_out = 0.002, 1.0, 3600.0
+    c.time_total = c.time_out * 72.0
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.sc("T_top")[:] = -5.0
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[0] = st.arr("thick")[0] * RHO_L
+    st.arr("S_abs")[0] = c.S_bu_bottom * st.arr("m")[0]
+    st.arr("H_abs")[0] = st.arr("m")[0] * c.T_bottom * C_L
+    return c, st
+
+
+def testcase4(ncol: int = 1, nlayer: int = 100, n_top: int = 20, n_bottom: int = 20):
+    """mo_init.f90:1127-1207: SHEBA / ERA-interim forced multi-year run (`Nlayer=100 = 20+60+20`)."""
+    c = default_config()
+    c.testcase = 4
+    c.nlayer, c.n_top, c.n_bottom = nlayer, n_top, n_bottom
+    c.atmoflux_flag, c.precip_flag, c.boundflux_flag = 2, 1, 2
+    c.snow_flush_flag, c.flush_heat_flag, c.snow_precip_flag = 1, 2, 1
+    c.T_bottom, c.S_bu_bottom = -1.0, 34.0
+    c.thick_0, c.time_out, c.dt = 0.01, 86400.0, 10.0
+    c.time_total = c.time_out * 365.0 * 4.5
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[:] = st.arr("thick") * RHO_L
+    st.arr("S_abs")[:] = c.S_bu_bottom * st.arr("m")
+    st.arr("H_abs")[:] = 0.0
+    return c, st
+
+
+def read_forcing(directory: str, length: int = LENGTH_INPUT):
+    """sub_input (mo_functions.f90:304-327): list-directed read of the first `length` values of
+    flux_sw/flux_lw/T2m/precip.txt.input; returns (fl_sw, fl_lw, T2m, precip)."""
+    out = []
+    for name in ("flux_sw", "flux_lw", "T2m", "precip"):
+        a = np.loadtxt(os.path.join(directory, name + ".txt.input")).ravel()[:length]
+        out.append(np.ascontiguousarray(a, dtype=np.float64))
+    return tuple(out)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x.copy()
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def ensemble_perturbation(ncol: int, col0: int = 0):
+    """dT2m_i in U(-2,2) K, precip scale 1+eps_i, eps_i in U(-0.3,0.3), from
+    splitmix64(column_id xor 0x5A5A2026); global column 0 is unperturbed.  col0 = first global column id
+    (multi-GPU shards regenerate their own slice)."""
+    with np.errstate(over="ignore"):
+        ids = np.arange(col0, col0 + ncol, dtype=np.uint64) ^ np.uint64(0x5A5A2026)
+        h1 = splitmix64(ids)
+        h2 = splitmix64(h1)
+    u1 = (h1 >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    u2 = (h2 >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    dT = -2.0 + 4.0 * u1
+    ps = 1.0 + (-0.3 + 0.6 * u2)
+    if col0 == 0 and ncol > 0:
+        dT[0] = 0.0
+        ps[0] = 1.0
+    return dT, ps
