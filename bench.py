@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched sea-ice column update on MI355X (BASELINE.json metric:
+column-timesteps/sec, achieved HBM GB/s vs peak).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One bench "step" = ONE launch of the hot path that advances every column `--substeps` model time steps
+(a launch is one pass of the time-loop body over the whole resident ensemble, repeated substeps times inside
+the kernel; columns never communicate).  Workload (config.workload): SURVEY.md section 8(d) cfg3 -- testcase 4 /
+SHEBA physics and forcing tables (boundflux 2, gravity drainage, flushing, flooding, snow), `--ncol` columns per
+GPU started from a spun-up single-column state (oracle checkpoint at day 200, committed fixture) with the
+per-column T2m / precipitation perturbation of cfg3.  The state is resident in HBM before the timed region.
+Multi-GPU: columns are sharded by rank, no data-path collective exists (weak scaling: per-GPU columns fixed).
+
+The JSON line also carries
+  roofline      algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (C port of the reference algorithm) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def load_checkpoint(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name))
+    from samsim_amd.capi import State
+    st = State(np.ascontiguousarray(z["lay"]), np.ascontiguousarray(z["scal"]), np.ascontiguousarray(z["n_active"]))
+    clock = dict(time=float(z["time"]), step=int(z["step"]), n_time_out=int(z["n_time_out"]),
+                 time_counter=int(z["time_counter"]), n_outputs=int(z["n_outputs"]))
+    return st, clock
+
+
+def workload(args):
+    from samsim_amd import testcases as tcs
+    if args.workload == "sheba":
+        cfg, _ = tcs.testcase4(1)
+        st, clock = load_checkpoint("tc4_spunup_state.npz")
+        z = np.load(os.path.join(ROOT, "tests", "golden", "sheba_forcing.npz"))
+        forcing = (z["fl_sw"], z["fl_lw"], z["T2m"], z["precip"])
+        name = "SHEBA/testcase-4 physics+forcing (cfg3), spun-up day-200 state, per-column perturbed T2m/precip"
+    else:
+        cfg, _ = tcs.testcase1(1)
+        st, clock = load_checkpoint("tc1_spunup_state.npz")
+        forcing = None
+        name = "testcase-1 physics (cfg2), spun-up state replicated to identical columns"
+    return cfg, st, clock, forcing, name
+
+
+def upload_replicated(solver, st1, ncol, chunk=65536):
+    """column 0 of st1 repeated over all columns of the handle, uploaded in chunks"""
+    rep = st1.replicate(min(chunk, ncol))
+    c0 = 0
+    while c0 < ncol:
+        n = min(chunk, ncol - c0)
+        solver.set_state(rep if n == rep.ncol else rep.window(0, n), c0)
+        c0 += n
+
+
+def cpu_baseline(cfg, st1, clock, forcing, col0, target_s):
+    """oracle (C port of the reference algorithm) on a bounded sample of the same workload"""
+    from samsim_amd import testcases as tcs
+    from tests.oracle_lib import oracle_solver
+    cores = len(os.sched_getaffinity(0))
+    ncol = 4 * cores
+    o = oracle_solver(cfg, ncol)
+    o.set_threads(cores)
+    if forcing is not None:
+        dT, ps = tcs.ensemble_perturbation(ncol, col0)
+        o.set_forcing(*forcing, dT, ps)
+    o.set_state(st1.replicate(ncol))
+    o.set_clock(**clock)
+    t = time.perf_counter()
+    o.step(50)
+    dt = time.perf_counter() - t
+    nsteps = max(50, int(50 * target_s / max(dt, 1e-3)))
+    t = time.perf_counter()
+    o.step(nsteps)
+    dt = time.perf_counter() - t
+    work0, _ = o.get_work()
+    return {"value": ncol * nsteps / dt, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{ncol} columns x {nsteps} steps of the same workload on {cores} OpenMP threads ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncol", type=int, default=1 << 20, help="columns per GPU")
+    ap.add_argument("--substeps", type=int, default=20, help="model time steps per launch")
+    ap.add_argument("--workload", choices=["sheba", "tc1"], default="sheba")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        # the data path has no collective; ranks only meet for the timing barrier and the max-over-ranks reduction,
+        # which run over gloo so that this process holds exactly one GPU runtime (the one the HIP library uses)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import samsim_amd
+    from samsim_amd import testcases as tcs
+
+    cfg, st1, clock, forcing, wname = workload(args)
+    ncol = args.ncol
+    col0 = rank * ncol
+    g = samsim_amd.hip_solver(cfg, ncol, device=local_rank)
+    if forcing is not None:
+        dT, ps = tcs.ensemble_perturbation(ncol, col0)
+        g.set_forcing(*forcing, dT, ps)
+    upload_replicated(g, st1, ncol)
+    g.set_clock(**clock)
+    g.set_output_window(0, 0)
+
+    def barrier():
+        g.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        g.step(args.substeps)
+    barrier()
+    work_before, _ = g.get_work()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(g.step_timed(args.substeps))
+    barrier()
+    wall = time.perf_counter() - t0
+    work_after, _ = g.get_work()
+    status = g.get_status()[0]
+    nfail = int((status != 0).sum())
+
+    wall_max, cells, fails = wall, float(work_after - work_before), float(nfail)
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t[0])
+        s = torch.tensor([cells, fails], dtype=torch.float64)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        cells, fails = float(s[0]), float(s[1])
+
+    if rank == 0:
+        timesteps = args.steps * args.substeps
+        value = world * ncol * timesteps / wall_max
+        nlayer = int(cfg.nlayer)
+        bytes_per_colstep = 16.0 * (4 * nlayer + 24)   # read + write once of the prognostic state
+        mean_ms = float(np.mean(kernel_ms))
+        achieved = bytes_per_colstep * ncol * args.substeps / (mean_ms * 1e-3) / 1e9
+        out = {
+            "metric": "column-timesteps/sec", "value": value, "unit": "column-timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; spun-up synthetic ensemble state"
+                    if args.workload == "sheba" else "synthetic: replicated spun-up testcase-1 state",
+            "config": {"workload": wname, "ncol_per_gpu": ncol, "nlayer": nlayer, "timesteps_per_step": args.substeps,
+                       "parallelism": f"columns sharded over {world} GPU(s), no collective"},
+            "layer_cell_updates_per_s": cells / wall_max,
+            "failed_columns": int(fails),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "samsim_step_kernel", "mean_launch_ms": mean_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, st1, clock, forcing, col0, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,9 @@ int samsim_set_forcing(samsim_handle *h, int32_t len, const double *fl_sw, const
                        const double *T2m, const double *precip,
                        const double *dT2m_col, const double *precip_scale_col);
 
-/* initial state of init(testcase) (mo_init.f90:141-1978) or a checkpoint; col0/ncols select a window */
+/* initial state of init(testcase) (mo_init.f90:141-1978) or a checkpoint; col0 and s->ncol select a window.
+ * The two perturbation slots SAMSIM_S_DT2M / SAMSIM_S_PRECIP_SCALE are owned by samsim_set_forcing: set_state
+ * ignores them, get_state returns them. */
 int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0);
 int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0);
 int samsim_set_clock(samsim_handle *h, const samsim_clock *c);

@@ -37,6 +37,11 @@ for variant in dat dump; do
   done
   "$FC" $FFLAGS -module-dir "$B" "$HERE/ref_hook/ref_driver.f90" $objs -o "$OUT/samsim_ref_$variant"
 done
+# function-level harness against the unmodified reference modules (objects of the dump variant)
+B=$OUT/build_dump
+FOBJS=""
+for m in mo_parameters mo_data mo_functions mo_init mo_thermo_functions mo_mass mo_grav_drain mo_output mo_layer_dynamics mo_flush mo_snow; do FOBJS="$FOBJS $B/$m.o"; done
+"$FC" $FFLAGS -module-dir "$B" "$HERE/ref_hook/func_harness.f90" $FOBJS -o "$OUT/samsim_ref_func"
 # run directory: forcing tables are symlinked (not copied) next to an output/ directory
 mkdir -p "$OUT/run/output"
 for f in flux_lw flux_sw T2m precip; do ln -sf "$REF/$f.txt.input" "$OUT/run/$f.txt.input"; done

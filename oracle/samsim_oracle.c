@@ -1496,7 +1496,8 @@ int oracle_set_state(oracle_handle *h, const samsim_state_soa *s, int64_t col0) 
       double *dst = lay_slot(c, a);
       for (int k = 1; k <= N; k++) dst[k] = s->lay[((size_t)a * N + (k - 1)) * nc + i];
     }
-    for (int j = 0; j < SAMSIM_NSCAL; j++) *scal_slot(c, j) = s->scal[(size_t)j * nc + i];
+    /* the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing and are not touched by set_state */
+    for (int j = 0; j < SAMSIM_S_DT2M; j++) *scal_slot(c, j) = s->scal[(size_t)j * nc + i];
     c->N_active = s->n_active[i];
     if (c->N_active < 1 || c->N_active > N) return SAMSIM_ERR_ARG;
   }

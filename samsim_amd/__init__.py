@@ -18,11 +18,12 @@ def load() -> _C.CDLL:
     """dlopen the HIP product library (fails loudly if it is not built)."""
     global _lib
     if _lib is None:
-        if not _os.path.exists(HIP_LIB_PATH):
+        path = _os.environ.get("SAMSIM_HIP_LIB", HIP_LIB_PATH)  # tuning variants of the same HIP library
+        if not _os.path.exists(path):
             raise RuntimeError(
-                f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-        _lib = _C.CDLL(HIP_LIB_PATH)
+        _lib = _C.CDLL(path)
         _lib.samsim_abi_version.restype = _C.c_int
         if _lib.samsim_abi_version() != capi.ABI_VERSION:
             raise RuntimeError("libsamsim_hip.so ABI version mismatch")

@@ -1,10 +1,10 @@
 """ctypes view of the C-ABI declared in include/samsim.h.
 
-The same struct layouts and call signatures are exported by the product library
-(``samsim_amd/csrc/libsamsim_hip.so``, prefix ``samsim_``) and -- for tests only -- by the CPU oracle
-(``oracle/liboracle.so``, prefix ``oracle_``).  This module only describes the interface; it never
-locates or loads the oracle by itself (``samsim_amd.load()`` loads the HIP library and fails loudly
-when it is missing).
+The struct layouts and call signatures are those of the product library
+(``samsim_amd/csrc/libsamsim_hip.so``, symbol prefix ``samsim_``).  ``Solver`` is parameterised by the library
+object and the symbol prefix so that the test-suite can drive a checker library that exports the same interface
+under another prefix; this module itself only ever describes the interface (``samsim_amd.load()`` loads the HIP
+library and fails loudly when it is missing -- there is no CPU fallback).
 """
 from __future__ import annotations
 
@@ -150,7 +150,7 @@ class Output:
 
 
 class Solver:
-    """One handle of the C-ABI (prefix 'samsim_' = HIP product, 'oracle_' = CPU oracle in tests)."""
+    """One handle of the C-ABI of include/samsim.h."""
 
     def __init__(self, lib: C.CDLL, prefix: str, cfg: Config, ncol: int, device: int = 0):
         self._lib = lib
@@ -160,12 +160,13 @@ class Solver:
         self.nlayer = int(cfg.nlayer)
         self._h = C.c_void_p()
         self._bind()
-        if prefix == "samsim_":
-            rc = self._f("create")(C.byref(cfg), C.c_int64(ncol), C.c_int32(device), C.byref(self._h))
-        else:
-            rc = self._f("create")(C.byref(cfg), C.c_int64(ncol), C.byref(self._h))
-        self._chk(rc, "create")
+        self._chk(self._create(device), "create")
         self._out_window = (0, 1)
+
+    def _create(self, device):
+        f = self._f("create")
+        f.argtypes, f.restype = [C.POINTER(Config), C.c_int64, C.c_int32, C.POINTER(C.c_void_p)], C.c_int
+        return f(C.byref(self.cfg), C.c_int64(self.ncol), C.c_int32(device), C.byref(self._h))
 
     # -- plumbing
     def _f(self, name):
@@ -192,20 +193,14 @@ class Solver:
         f.argtypes, f.restype = [vp], C.c_int64
         f = self._f("destroy")
         f.argtypes, f.restype = [vp], None
-        if self._p == "samsim_":
-            f = self._f("create")
-            f.argtypes, f.restype = [C.POINTER(Config), i64, i32, C.POINTER(vp)], C.c_int
-            f = self._f("step_timed")
-            f.argtypes, f.restype = [vp, i64, C.POINTER(C.c_double)], C.c_int
-            f = self._f("synchronize")
-            f.argtypes, f.restype = [vp], C.c_int
-        else:
-            f = self._f("create")
-            f.argtypes, f.restype = [C.POINTER(Config), i64, C.POINTER(vp)], C.c_int
-            f = self._f("step_part_b")
-            f.argtypes, f.restype = [vp], C.c_int
-            f = self._f("set_threads")
-            f.argtypes, f.restype = [vp, C.c_int], None
+        self._bind_extra()
+
+    def _bind_extra(self):
+        vp, i64 = C.c_void_p, C.c_int64
+        f = self._f("step_timed")
+        f.argtypes, f.restype = [vp, i64, C.POINTER(C.c_double)], C.c_int
+        f = self._f("synchronize")
+        f.argtypes, f.restype = [vp], C.c_int
 
     # -- API
     def set_forcing(self, fl_sw, fl_lw, T2m, precip, dT2m=None, precip_scale=None):
@@ -249,14 +244,7 @@ class Solver:
         return ms.value
 
     def synchronize(self):
-        if self._p == "samsim_":
-            self._chk(self._f("synchronize")(self._h), "synchronize")
-
-    def step_part_b(self):
-        self._chk(self._f("step_part_b")(self._h), "step_part_b")
-
-    def set_threads(self, n):
-        self._f("set_threads")(self._h, n)
+        self._chk(self._f("synchronize")(self._h), "synchronize")
 
     def steps_to_output(self) -> int:
         return int(self._f("steps_to_output")(self._h))

@@ -1,0 +1,430 @@
+// samsim_capi.cpp -- host side of the C-ABI declared in include/samsim.h.
+//
+// Owns the HBM allocations of a handle (layout: samsim_device.h), mirrors the uniform clock of the ensemble on
+// the host (time, step, output counter, forcing-table cursor are the same for every column, so nothing has to
+// be read back to know them) and launches the step kernel on the handle's HIP stream.  There is no CPU
+// implementation of the physics here or anywhere else in the product: without a HIP device every entry point
+// that would compute returns SAMSIM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "samsim_device.h"
+
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, long long ncol, hipStream_t stream);
+
+namespace {
+
+constexpr int kRing = 8;
+
+thread_local char g_last_hip_error[256] = "";
+
+bool hip_ok(hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s: %s", what, hipGetErrorString(e));
+  return false;
+}
+#define HIPCHK(call)                                  \
+  do {                                                \
+    if (!hip_ok((call), #call)) return SAMSIM_ERR_HIP; \
+  } while (0)
+
+}  // namespace
+
+struct samsim_handle {
+  samsim_config cfg{};
+  long long ncol = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // device memory
+  double *lay = nullptr, *scal = nullptr;
+  int32_t *n_active = nullptr, *status = nullptr, *err_layer = nullptr;
+  long long *err_step = nullptr, *work = nullptr;
+  double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
+  int32_t flen = 0;
+  double *out_lay = nullptr, *out_scal = nullptr;
+  int32_t *out_n_active = nullptr;
+  long long out_col0 = 0, out_ncols = 0;
+  // parameter ring (pinned host + device), one event per slot
+  DevParams *h_params = nullptr, *d_params = nullptr;
+  hipEvent_t slot_done[kRing]{};
+  int slot = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // uniform clock, mirrored on the host
+  samsim_clock clk{};
+  bool snap_valid = false;
+  double snap_time = 0.0;
+  long long snap_step = 0;
+  double p17 = 0, p14 = 0, tf_c3 = 0;
+};
+
+namespace {
+
+int validate(const samsim_config &c) {
+  if (c.struct_size != (int32_t)sizeof(samsim_config)) return SAMSIM_ERR_ABI;
+  if (c.nlayer < 3 || c.nlayer > SAMSIM_MAX_NLAYER) return SAMSIM_ERR_ARG;
+  if (c.n_top < 3 || c.n_bottom < 1 || c.n_middle < 1 || c.n_top + c.n_middle + c.n_bottom != c.nlayer) return SAMSIM_ERR_ARG;
+  if (!(c.dt > 0.0) || !(c.thick_0 > 0.0) || c.i_time_out < 0) return SAMSIM_ERR_ARG;
+  auto in = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
+  if (!in(c.boundflux_flag, {1, 2})) return SAMSIM_ERR_UNSUPPORTED;
+  if (c.boundflux_flag == 2 && c.atmoflux_flag != 2) return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.atmoflux_flag, {1, 2, 3})) return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.grav_flag, {1, 2}) || c.prescribe_flag != 1 || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
+    return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 5}) || !in(c.flood_flag, {1, 2}))
+    return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || c.tank_flag != 1)
+    return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.albedo_flag, {1, 2}) || !in(c.freeboard_snow_flag, {0, 1}) || !in(c.snow_flush_flag, {0, 1}) || c.bgc_flag != 1)
+    return SAMSIM_ERR_UNSUPPORTED;
+  return SAMSIM_OK;
+}
+
+template <typename T>
+hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+// fill a [rows][ncol] device block with one value per row-set
+__global__ void fill_rows(double *dst, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+__global__ void fill_i32(int32_t *dst, size_t n, int32_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+hipError_t fill(double *dst, size_t n, double v, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, v);
+  return hipGetLastError();
+}
+
+void advance_clock(samsim_handle *h, long long nsteps) {
+  samsim_clock &k = h->clk;
+  const samsim_config &c = h->cfg;
+  for (long long s = 0; s < nsteps; ++s) {
+    if (c.atmoflux_flag == 2) {
+      const double ti = ((double)(float)k.time_counter - 1.0) * 3600.0 * 3.0;
+      if (k.time > ti) k.time_counter += 1;
+      if (k.time_counter > h->flen) k.time_counter = h->flen;
+    }
+    const bool out = (k.n_time_out == c.i_time_out) || (k.step + 1 == 1);
+    if (out) {
+      k.n_time_out = 0;
+      k.n_outputs += 1;
+      h->snap_valid = h->out_ncols > 0;
+      h->snap_time = k.time;
+      h->snap_step = k.step + 1;
+    } else {
+      k.n_time_out += 1;
+    }
+    k.time = k.time + c.dt;
+    k.step += 1;
+  }
+}
+
+int launch(samsim_handle *h, long long nsteps) {
+  if (nsteps <= 0) return SAMSIM_OK;
+  if (h->cfg.atmoflux_flag == 2 && h->cfg.boundflux_flag == 2 && !h->f_sw) return SAMSIM_ERR_ARG;
+  const int s = h->slot;
+  h->slot = (h->slot + 1) % kRing;
+  HIPCHK(hipEventSynchronize(h->slot_done[s]));
+  DevParams &p = h->h_params[s];
+  p.cfg = h->cfg;
+  p.lay = h->lay; p.scal = h->scal; p.n_active = h->n_active; p.status = h->status; p.err_layer = h->err_layer;
+  p.err_step = h->err_step; p.work = h->work;
+  p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
+  p.ncol = h->ncol;
+  p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
+  p.nsteps = nsteps;
+  p.out_lay = h->out_lay; p.out_scal = h->out_scal; p.out_n_active = h->out_n_active;
+  p.out_col0 = h->out_col0; p.out_ncols = h->out_ncols;
+  p.p17 = h->p17; p.p14 = h->p14; p.tf_c3 = h->tf_c3;
+  HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(samsim_launch_step(&h->d_params[s], h->ncol, h->stream));
+  HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
+  advance_clock(h, nsteps);
+  return SAMSIM_OK;
+}
+
+int use(samsim_handle *h) {
+  if (!h) return SAMSIM_ERR_ARG;
+  HIPCHK(hipSetDevice(h->device));
+  return SAMSIM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int samsim_abi_version(void) { return SAMSIM_ABI_VERSION; }
+
+int samsim_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *samsim_strerror(int code) {
+  switch (code) {
+    case SAMSIM_OK: return "ok";
+    case SAMSIM_ERR_ARG: return "bad argument";
+    case SAMSIM_ERR_UNSUPPORTED: return "flag value not supported by the HIP path";
+    case SAMSIM_ERR_HIP: return g_last_hip_error[0] ? g_last_hip_error : "HIP error";
+    case SAMSIM_ERR_NO_DEVICE: return "no HIP device";
+    case SAMSIM_ERR_NO_OUTPUT: return "no output snapshot has been taken";
+    case SAMSIM_ERR_ABI: return "samsim_config.struct_size does not match this library";
+    case SAMSIM_ERR_NOMEM: return "out of memory";
+  }
+  return "unknown error";
+}
+
+int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim_handle **out) {
+  if (!cfg || !out || ncol <= 0) return SAMSIM_ERR_ARG;
+  int rc = validate(*cfg);
+  if (rc) return rc;
+  if (device < 0 || device >= samsim_device_count()) return SAMSIM_ERR_NO_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  samsim_handle *h = new (std::nothrow) samsim_handle();
+  if (!h) return SAMSIM_ERR_NOMEM;
+  h->cfg = *cfg; h->ncol = ncol; h->device = device;
+  h->clk = samsim_clock{0.0, 0, 0, 1, 0};
+  h->p17 = std::pow(10.0, -17.0);
+  h->p14 = std::pow(10.0, -14.0);
+  h->tf_c3 = (double)(5.33f * std::pow(10.0f, -7.0f));
+  const size_t N = (size_t)cfg->nlayer, nc = (size_t)ncol;
+  bool ok = hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
+  ok = ok && hip_ok(dalloc(&h->lay, (size_t)DEV_NARR * N * nc), "hipMalloc lay");
+  ok = ok && hip_ok(dalloc(&h->scal, (size_t)SAMSIM_NSCAL * nc), "hipMalloc scal");
+  ok = ok && hip_ok(dalloc(&h->n_active, nc), "hipMalloc n_active");
+  ok = ok && hip_ok(dalloc(&h->status, nc), "hipMalloc status");
+  ok = ok && hip_ok(dalloc(&h->err_layer, nc), "hipMalloc err_layer");
+  ok = ok && hip_ok(dalloc(&h->err_step, nc), "hipMalloc err_step");
+  ok = ok && hip_ok(dalloc(&h->work, nc), "hipMalloc work");
+  ok = ok && hip_ok(dalloc(&h->d_params, (size_t)kRing), "hipMalloc params");
+  ok = ok && hip_ok(hipHostMalloc((void **)&h->h_params, sizeof(DevParams) * kRing, hipHostMallocDefault), "hipHostMalloc params");
+  for (int i = 0; ok && i < kRing; ++i) ok = hip_ok(hipEventCreateWithFlags(&h->slot_done[i], hipEventDisableTiming), "hipEventCreate");
+  ok = ok && hip_ok(hipEventCreate(&h->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&h->ev1), "hipEventCreate");
+  if (ok) {
+    // sub_allocate zeros (mo_init.f90:2081-2087) and the defaults of mo_init.f90:1982-1990
+    ok = hip_ok(hipMemsetAsync(h->lay, 0, sizeof(double) * DEV_NARR * N * nc, h->stream), "memset lay");
+    ok = ok && hip_ok(hipMemsetAsync(h->scal, 0, sizeof(double) * SAMSIM_NSCAL * nc, h->stream), "memset scal");
+    ok = ok && hip_ok(hipMemsetAsync(h->status, 0, sizeof(int32_t) * nc, h->stream), "memset");
+    ok = ok && hip_ok(hipMemsetAsync(h->err_layer, 0, sizeof(int32_t) * nc, h->stream), "memset");
+    ok = ok && hip_ok(hipMemsetAsync(h->err_step, 0, sizeof(long long) * nc, h->stream), "memset");
+    ok = ok && hip_ok(hipMemsetAsync(h->work, 0, sizeof(long long) * nc, h->stream), "memset");
+    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_T * N * nc, N * nc, cfg->T_bottom, h->stream), "fill T");
+    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_S_BU * N * nc, N * nc, cfg->S_bu_bottom, h->stream), "fill S_bu");
+    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_PSI_L * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
+    ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream), "fill precip_scale");
+    if (ok) {
+      hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->n_active, nc, 1);
+      ok = hip_ok(hipGetLastError(), "fill n_active");
+    }
+    ok = ok && hip_ok(hipStreamSynchronize(h->stream), "sync");
+  }
+  if (!ok) { samsim_destroy(h); return SAMSIM_ERR_HIP; }
+  rc = samsim_set_output_window(h, 0, 1);
+  if (rc) { samsim_destroy(h); return rc; }
+  *out = h;
+  return SAMSIM_OK;
+}
+
+void samsim_destroy(samsim_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
+  (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
+  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
+  (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
+  (void)hipFree(h->d_params);
+  if (h->h_params) (void)hipHostFree(h->h_params);
+  for (int i = 0; i < kRing; ++i) if (h->slot_done[i]) (void)hipEventDestroy(h->slot_done[i]);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int samsim_set_forcing(samsim_handle *h, int32_t len, const double *fl_sw, const double *fl_lw, const double *T2m,
+                       const double *precip, const double *dT2m_col, const double *precip_scale_col) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (len < 2 || !fl_sw || !fl_lw || !T2m || !precip) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
+  h->f_sw = h->f_lw = h->f_T2m = h->f_precip = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)len;
+  HIPCHK(dalloc(&h->f_sw, (size_t)len)); HIPCHK(dalloc(&h->f_lw, (size_t)len));
+  HIPCHK(dalloc(&h->f_T2m, (size_t)len)); HIPCHK(dalloc(&h->f_precip, (size_t)len));
+  HIPCHK(hipMemcpy(h->f_sw, fl_sw, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->f_lw, fl_lw, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->f_T2m, T2m, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->f_precip, precip, bytes, hipMemcpyHostToDevice));
+  h->flen = len;
+  const size_t nc = (size_t)h->ncol;
+  if (dT2m_col) HIPCHK(hipMemcpy(h->scal + (size_t)SAMSIM_S_DT2M * nc, dT2m_col, sizeof(double) * nc, hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(h->scal + (size_t)SAMSIM_S_DT2M * nc, 0, sizeof(double) * nc));
+  if (precip_scale_col) {
+    HIPCHK(hipMemcpy(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, precip_scale_col, sizeof(double) * nc, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return SAMSIM_OK;
+}
+
+static int check_soa(samsim_handle *h, const samsim_state_soa *s, int64_t col0) {
+  if (!s || !s->lay || !s->scal || !s->n_active) return SAMSIM_ERR_ARG;
+  if (s->nlayer != h->cfg.nlayer || s->ncol <= 0 || col0 < 0 || col0 + s->ncol > h->ncol) return SAMSIM_ERR_ARG;
+  if (s->narr != SAMSIM_NPROG && s->narr != SAMSIM_NARR) return SAMSIM_ERR_ARG;
+  return SAMSIM_OK;
+}
+
+int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0) {
+  int rc = use(h);
+  if (rc) return rc;
+  rc = check_soa(h, s, col0);
+  if (rc) return rc;
+  const size_t N = (size_t)s->nlayer, nc = (size_t)h->ncol, w = (size_t)s->ncol;
+  for (size_t i = 0; i < w; ++i) if (s->n_active[i] < 1 || s->n_active[i] > (int)N) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy2D(h->lay + col0, nc * sizeof(double), s->lay, w * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
+                     hipMemcpyHostToDevice));
+  // the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing: set_state leaves them alone
+  HIPCHK(hipMemcpy2D(h->scal + col0, nc * sizeof(double), s->scal, w * sizeof(double), w * sizeof(double), (size_t)SAMSIM_S_DT2M,
+                     hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->n_active + col0, s->n_active, w * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->status + col0, 0, w * sizeof(int32_t)));
+  return SAMSIM_OK;
+}
+
+int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
+  int rc = use(h);
+  if (rc) return rc;
+  rc = check_soa(h, s, col0);
+  if (rc) return rc;
+  const size_t N = (size_t)s->nlayer, nc = (size_t)h->ncol, w = (size_t)s->ncol;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy2D(s->lay, w * sizeof(double), h->lay + col0, nc * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
+                     hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(s->scal, w * sizeof(double), h->scal + col0, nc * sizeof(double), w * sizeof(double), (size_t)SAMSIM_NSCAL,
+                     hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(s->n_active, h->n_active + col0, w * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SAMSIM_OK;
+}
+
+int samsim_set_clock(samsim_handle *h, const samsim_clock *c) {
+  if (!h || !c || c->time_counter < 1 || c->step < 0) return SAMSIM_ERR_ARG;
+  h->clk = *c;
+  return SAMSIM_OK;
+}
+
+int samsim_get_clock(samsim_handle *h, samsim_clock *c) {
+  if (!h || !c) return SAMSIM_ERR_ARG;
+  *c = h->clk;
+  return SAMSIM_OK;
+}
+
+int samsim_step(samsim_handle *h, int64_t nsteps) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (nsteps < 0) return SAMSIM_ERR_ARG;
+  return launch(h, nsteps);
+}
+
+int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (nsteps < 0 || !kernel_ms) return SAMSIM_ERR_ARG;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  rc = launch(h, nsteps);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *kernel_ms = (double)ms;
+  return SAMSIM_OK;
+}
+
+int samsim_synchronize(samsim_handle *h) {
+  int rc = use(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return SAMSIM_OK;
+}
+
+int64_t samsim_steps_to_output(samsim_handle *h) {
+  if (!h) return 0;
+  if (h->clk.step == 0) return 1;
+  return (int64_t)(h->cfg.i_time_out - h->clk.n_time_out) + 1;
+}
+
+int samsim_set_output_window(samsim_handle *h, int64_t col0, int64_t ncols) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
+  h->out_lay = h->out_scal = nullptr; h->out_n_active = nullptr;
+  h->out_col0 = col0; h->out_ncols = ncols; h->snap_valid = false;
+  if (ncols > 0) {
+    const size_t N = (size_t)h->cfg.nlayer, w = (size_t)ncols;
+    HIPCHK(dalloc(&h->out_lay, (size_t)SAMSIM_NARR * N * w));
+    HIPCHK(dalloc(&h->out_scal, (size_t)SAMSIM_NSCAL * w));
+    HIPCHK(dalloc(&h->out_n_active, w));
+    HIPCHK(hipMemset(h->out_lay, 0, sizeof(double) * SAMSIM_NARR * N * w));
+    HIPCHK(hipMemset(h->out_scal, 0, sizeof(double) * SAMSIM_NSCAL * w));
+    HIPCHK(hipMemset(h->out_n_active, 0, sizeof(int32_t) * w));
+  }
+  return SAMSIM_OK;
+}
+
+int samsim_get_output(samsim_handle *h, samsim_output_soa *o) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!o || !o->lay || !o->scal || !o->n_active || o->ncols != h->out_ncols || o->nlayer != h->cfg.nlayer) return SAMSIM_ERR_ARG;
+  if (!h->snap_valid || h->out_ncols == 0) return SAMSIM_ERR_NO_OUTPUT;
+  const size_t N = (size_t)o->nlayer, w = (size_t)o->ncols;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(o->lay, h->out_lay, sizeof(double) * SAMSIM_NARR * N * w, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o->scal, h->out_scal, sizeof(double) * SAMSIM_NSCAL * w, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(o->n_active, h->out_n_active, sizeof(int32_t) * w, hipMemcpyDeviceToHost));
+  o->time = h->snap_time;
+  o->step = h->snap_step;
+  return SAMSIM_OK;
+}
+
+int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t *layer) {
+  int rc = use(h);
+  if (rc) return rc;
+  const size_t nc = (size_t)h->ncol;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (status) HIPCHK(hipMemcpy(status, h->status, sizeof(int32_t) * nc, hipMemcpyDeviceToHost));
+  if (step) HIPCHK(hipMemcpy(step, h->err_step, sizeof(long long) * nc, hipMemcpyDeviceToHost));
+  if (layer) HIPCHK(hipMemcpy(layer, h->err_layer, sizeof(int32_t) * nc, hipMemcpyDeviceToHost));
+  return SAMSIM_OK;
+}
+
+int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps) {
+  int rc = use(h);
+  if (rc) return rc;
+  const size_t nc = (size_t)h->ncol;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<long long> w(nc);
+  HIPCHK(hipMemcpy(w.data(), h->work, sizeof(long long) * nc, hipMemcpyDeviceToHost));
+  long long tot = 0;
+  for (size_t i = 0; i < nc; ++i) tot += w[i];
+  if (layer_cell_updates) *layer_cell_updates = tot;
+  if (column_steps) *column_steps = (int64_t)h->clk.step * (int64_t)h->ncol;
+  return SAMSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// samsim_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
+//
+// HBM layout (one allocation per handle, sized for ncol columns of nlayer layers):
+//   lay  [DEV_NARR][nlayer][ncol] float64   layer arrays, column fastest: a wave's 64 lanes read 512
+//                                           contiguous bytes for every (array, layer) pair
+//   scal [SAMSIM_NSCAL][ncol]     float64   per-column scalars
+//   n_active/status/err_layer [ncol] int32, err_step/work [ncol] int64
+// One GPU thread owns one column for the whole launch; a launch advances every column `nsteps` time steps.
+#ifndef SAMSIM_DEVICE_H
+#define SAMSIM_DEVICE_H
+
+#include "../../include/samsim.h"
+
+// device-internal layer arrays: the public ones (enum samsim_layer_array) followed by scratch
+enum dev_layer_array {
+  D_V_EX = SAMSIM_NARR,   // expelled brine volume V_ex(k) (mo_thermo_functions.f90:157); reused as R(k) in flush3
+  D_FLM,                  // not stored by the fused passes; kept for debugging
+  DEV_NARR
+};
+
+struct DevParams {
+  samsim_config cfg;
+  double *lay;
+  double *scal;
+  int32_t *n_active;
+  int32_t *status;
+  int32_t *err_layer;
+  long long *err_step;
+  long long *work;
+  const double *f_sw, *f_lw, *f_T2m, *f_precip;
+  int32_t flen;
+  long long ncol;
+  // uniform clock at launch (mo_data: time, i, n_time_out, time_counter)
+  double time0;
+  long long step0;
+  int32_t n_time_out0;
+  int32_t time_counter0;
+  long long nsteps;
+  // output snapshot window
+  double *out_lay;       // [SAMSIM_NARR][nlayer][out_ncols]
+  double *out_scal;      // [SAMSIM_NSCAL][out_ncols]
+  int32_t *out_n_active; // [out_ncols]
+  long long out_col0, out_ncols;
+  // host-evaluated constants: 10**(-17), 10**(-14) (mo_grav_drain.f90:105,112) and the float32 product
+  // 5.33*10.0**(-7.0) of func_T_freeze (mo_functions.f90:246)
+  double p17, p14, tf_c3;
+};
+
+#endif

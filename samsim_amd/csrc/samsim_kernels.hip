@@ -1,0 +1,1568 @@
+// samsim_kernels.hip -- hand-written CDNA4 (gfx950) kernel for the per-timestep 1-D sea-ice column update.
+//
+// What it computes: the body of the reference time loop, pgriewank/SAMSIM mo_grotz.f90:182-835, for `ncol`
+// independent columns, `nsteps` steps per launch.  One lane owns one column for the whole launch (columns
+// never communicate), state lives in HBM as [array][layer][column] float64 so that every per-layer access of
+// a wave is one contiguous 512-byte line, and a column's layers are walked sequentially inside the lane with
+// the neighbour values (k-1, k, k+1) carried in registers.  No MFMA (there is no contraction in this path),
+// no LDS (the stencil neighbours are register-carried), no cross-lane traffic.
+//
+// The sequential structure inside a column is dictated by the reference: getT's Newton iteration is seeded
+// with the temperature of the layer below (mo_grotz.f90:298-303) and stops at |f| <= 1 J/kg, so the result
+// depends on the guess (hard part 1) and the bottom->top chain has to be reproduced.
+//
+// Sweeps per step (direction, what is fused; reference lines in the functions below):
+//   S1  up    S_bu,H -> getT chain -> S_br -> Expulsion; permeability + suffix scans -> Rayleigh number
+//   P2  down  expulsion_flux recurrence + mass_transfer + S_bu refresh
+//   P3  down  gravity-drainage fluxes + return-flow mass_transfer + Beer-law transmittance
+//   P4  up    conductive stencil + explicit enthalpy update + second getT chain
+//   rare: freeboard (2 down), flush3 (1 up + 1 down), flood, snow, layer_dynamics (regrid)
+// The reference's O(N^2) loops (harmonic-mean permeability, freeboard search) are O(N) scans here; sums are
+// therefore associated differently (1e-16 relative), everything else follows the reference's operation order.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "samsim_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------- constants, mo_parameters.f90:38-112
+// `pi` and `grav` are default REAL (float32) in the reference (mo_parameters.f90:38-39)
+constexpr double pi_f = (double)3.1415f;
+constexpr double grav_f = (double)9.8061f;
+constexpr double k_s = 2.2, k_l = 0.523;
+constexpr double c_s = 2020.0, c_s_beta = 7.6973, c_l = 3400.0;
+constexpr double rho_s = 920.0, rho_l = 1028.0, latent_heat = 333500.0, zeroK = 273.15;
+// `0.8_wp*1e-3`: float32 literal factor (mo_parameters.f90:56,57,59)
+constexpr double bbeta = 0.8 * (double)1e-3f;
+constexpr double mu = 2.55 * (double)1e-3f;
+constexpr double kappa_l = k_l / rho_l / c_l;
+constexpr double sigma = 5.6704 * (double)1e-8f;
+constexpr double psi_s_min = 0.05, neg_free = -0.05;
+constexpr double x_grav = 0.000584, ray_crit = 4.89;
+constexpr double para_flush_horiz = 1.0;
+constexpr double psi_s_top_min = 0.40, ratio_flood = 1.50, ref_salinity = 34.0;
+constexpr double rho_snow = 330.0, gas_snow_ice2 = 0.20;
+constexpr double emissivity_ice = 0.95, emissivity_snow = 1.00, penetr = 0.30, extinc = 2.00;
+constexpr double Turb_A = 0.1 * 0.05 * rho_l / 86400.0;
+constexpr double Turb_B = 0.05;
+
+struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
+  double c2, c3, c4, d2, d3, d4;
+};
+
+struct Col {
+  double *lay;  // already offset by the column index
+  size_t ncol;
+  int N;
+  int Na;       // N_active
+  int status, err_layer;
+  long long err_step;
+  long long step;  // completed steps; i = step + 1
+  // per-column scalars (enum samsim_scalar)
+  double m_snow, H_abs_snow, S_abs_snow, thick_snow, psi_s_snow, psi_l_snow, psi_g_snow, T_snow, phi_s;
+  double T_top, melt_thick, T2m, liquid_precip, solid_precip, fl_q_bottom;
+  double grav_drain, grav_salt, grav_temp, melt_out1, melt_out2, melt_out3, melt_err;
+  double freeboard, T_freeze, albedo, fl_sw, fl_lw, melt_thick_snow, fl_Q_snow;
+  double energy_stored, freshwater, total_resist, thickness, bulk_salin;
+  double dT2m, precip_scale;
+  // per-step temporaries that cross sweeps
+  double fl_Q1;      // fl_Q(1)
+  double frad;       // fl_rad(N_active)
+  double min_psi_s;  // MINVAL(psi_s(1:N_active)) of this step's Expulsion
+};
+
+#define LAY(a, k) c.lay[((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol]
+#define STOPC(code, layer)            \
+  do {                                \
+    if (!c.status) {                  \
+      c.status = (code);              \
+      c.err_step = c.step + 1;        \
+      c.err_layer = (layer);          \
+    }                                 \
+    return;                           \
+  } while (0)
+
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+
+// func_S_br without / with the S_bu clamp, mo_thermo_functions.f90:308-360.  flang lowers T**2._wp and T**3._wp
+// to multiplications (verified bit for bit against the flang build), so do we.
+__device__ __forceinline__ double S_br_poly(const Salt &s, double T) { return 0.0 + s.c2 * T + s.c3 * (T * T) + s.c4 * (T * T * T); }
+__device__ __forceinline__ double S_br_clamped(const Salt &s, double T, double S_bu) {
+  double v = S_br_poly(s, T);
+  return v < S_bu ? S_bu : v;
+}
+// func_ddT_S_br, mo_thermo_functions.f90:380-414 (derivative-only clamp below -20 C)
+__device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
+  const double T_crit = -20.0;
+  double d = s.d2 + 2.0 * s.d3 * T + 3.0 * s.d4 * (T * T);
+  if (T < T_crit) d = s.d2 + 2.0 * s.d3 * T_crit + 3.0 * s.d4 * (T_crit * T_crit);
+  return d;
+}
+
+// getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
+// Returns 99 (the reference's STOP code) when 260 iterations do not converge.
+__device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out) {
+  double T = H / c_l, phi = phi_out;
+  int rc = 0;
+  if (S_br_clamped(s, T, S_bu) > S_bu && S_bu > 0.001) {
+    double T_fr = -1.0, T_0, f, ddT_f, sb;
+    // freezing temperature; tolerance 0.0001 is a float32 literal (:87)
+    while (fabs(S_br_poly(s, T_fr) / S_bu - 1.0) > (double)0.0001f) {
+      T_0 = T_fr;
+      f = S_br_poly(s, T_0) - S_bu;
+      ddT_f = ddT_S_br(s, T_0);
+      T_fr = T_0 - f / ddT_f;
+    }
+    T_0 = T_in;
+    sb = S_br_poly(s, T_0);
+    f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
+    ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+    T = T_0 - f / ddT_f;
+    int i = 0;
+    while (fabs(f) > 1.0) {
+      T_0 = T;
+      if (T_0 > 0.0 || T_0 < -200.0) T_0 = T_fr;
+      sb = S_br_poly(s, T_0);
+      f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.0000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
+      ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+      T = T_0 - f / ddT_f;
+      if (++i == 260) { rc = 99; break; }
+    }
+    phi = 1.0 - S_bu / S_br_clamped(s, T, S_bu);
+  } else if (S_bu < 0.001) {
+    if (H > 0.0) { phi = 0.0; T = H / c_l; }
+    else if (H <= -latent_heat) { phi = 1.0; T = (H + latent_heat) / c_s; }
+    else if (H <= 0.0 && -latent_heat < H) { T = 0.0; phi = -H / latent_heat; }
+  } else {
+    phi = 0.0;
+  }
+  T_out = T;
+  phi_out = phi;
+  return rc;
+}
+
+// func_density, mo_functions.f90:51-62
+__device__ double func_density(double T, double S) {
+  double density_0 = 999.842594 + 6.8 / 100.0 * T;
+  return density_0 + 0.825 * S + (-5.7 / 1000.0) * pow(dmax(S, 0.0), 1.5);
+}
+
+// func_T_freeze, mo_functions.f90:239-250 (float32 products of default-REAL literals)
+__device__ double func_T_freeze(double S_bu, int salt_flag, double tf_c3) {
+  if (salt_flag == 2) {
+    return -0.0592 * S_bu - (double)9.37f * (S_bu * S_bu) - tf_c3 * (S_bu * S_bu * S_bu);
+  } else {
+    const float a = 1.710523f * 1e-3f, b = 2.154996f * 1e-4f;
+    return -0.0575 * S_bu + (double)a * pow(S_bu, 1.5) - (double)b * (S_bu * S_bu);
+  }
+}
+
+// func_albedo, mo_functions.f90:157-208 (float32 literals)
+__device__ double func_albedo(double thick_snow, double T_snow, double psi_l, double thick_min, int albedo_flag) {
+  const double ice_dry = (double)0.75f, ice_wet = (double)0.6f, snow_dry = (double)0.85f, snow_wet = (double)0.75f,
+               water = (double)0.2f;
+  double albedo;
+  if (thick_snow > thick_min) {
+    albedo = (T_snow < (double)(-0.01f)) ? snow_dry : snow_wet;
+    albedo = ice_dry + (albedo - ice_dry) * dmin(1.0, thick_snow / 0.3);
+  } else {
+    if (psi_l > 0.9) albedo = water;
+    else if (psi_l > 0.6) albedo = ice_wet + (water - ice_wet) * ((psi_l - 0.6) / 0.3);
+    else if (psi_l > 0.2) albedo = ice_wet;
+    else albedo = ice_dry;
+  }
+  if (albedo_flag == 1) {
+    if (thick_snow > thick_min) albedo = (T_snow < (double)(-0.01f)) ? snow_dry : snow_wet;
+    else albedo = (psi_l < (double)0.8f) ? ice_dry : water;
+  }
+  return albedo;
+}
+
+// func_k_snow, mo_snow.f90:560-573
+__device__ double func_k_snow(double m_snow, double thick_snow) {
+  const double c0 = 0.138, c1 = -1.01 / 1000.0, c2 = 3.233 / 1000000.0;
+  double r = m_snow / thick_snow;
+  double k_snow = c0 + c1 * m_snow / thick_snow + c2 * (r * r);
+  return k_snow + (double)0.15f;
+}
+
+// 3-hourly table time axis, mo_functions.f90:323-325
+__device__ __forceinline__ double time_input(int k) { return ((double)(float)k - 1.0) * 3600.0 * 3.0; }
+
+struct Ctx {
+  const DevParams *p;
+  Salt salt;
+  double p17, p14, tf_c3;
+};
+
+// ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
+// O(N): one pass for the column totals, one pass for the waterline search with prefix sums (the reference
+// recomputes the suffix sums for every candidate layer).
+__device__ double func_freeboard(Col &c, const Ctx &x) {
+  const int Na = c.Na;
+  double snowmass = (x.p->cfg.freeboard_snow_flag == 0) ? c.m_snow : 0.0;
+  double A = 0.0, G = 0.0;
+  for (int k = 1; k <= Na; ++k) {
+    double th = LAY(SAMSIM_A_THICK, k);
+    A += LAY(SAMSIM_A_PSI_S, k) * th;
+    G += LAY(SAMSIM_A_PSI_G, k) * th;
+  }
+  double buoy = A * (rho_l - rho_s) + G * rho_l;
+  double freeboard;
+  if (snowmass > buoy) {
+    freeboard = (buoy - snowmass) / rho_l;
+  } else {
+    double Ap = 0.0, Gp = 0.0, Mp = 0.0, Tp = 0.0;  // prefix sums over 1..k-1
+    double test2 = 0.0, mk = 0.0, thk = 1.0;
+    int k = 0;
+    for (;;) {
+      ++k;
+      mk = LAY(SAMSIM_A_M, k);
+      thk = LAY(SAMSIM_A_THICK, k);
+      double a = LAY(SAMSIM_A_PSI_S, k) * thk, g = LAY(SAMSIM_A_PSI_G, k) * thk;
+      // buoyancy of the layers below k, mass of layers 1..k
+      test2 = (k == Na) ? 0.0 : ((A - (Ap + a)) * (rho_l - rho_s) + (G - (Gp + g)) * rho_l);
+      double test1 = (Mp + mk) + snowmass;
+      if (!(test1 < test2) || k >= Na) break;
+      Ap += a; Gp += g; Mp += mk; Tp += thk;
+    }
+    double test1 = Mp + snowmass;
+    freeboard = test2 - test1 + (rho_l - mk / thk) * thk;
+    freeboard = freeboard / rho_l;
+    freeboard = freeboard + Tp;
+  }
+  return freeboard;
+}
+
+// ---------------------------------------------------------------- snow, mo_snow.f90
+// snow_coupling, mo_snow.f90:61-104.  The reference passes T_snow / T as both the guess and the result of getT;
+// by-reference argument passing makes the guess H/c_l (getT's first statement overwrites it).
+__device__ void snow_coupling(Col &c, const Ctx &x) {
+  const Salt &s = x.salt;
+  double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), S_bu = LAY(SAMSIM_A_S_BU, 1);
+  double T = LAY(SAMSIM_A_T, 1), phi = LAY(SAMSIM_A_PHI, 1), H;
+  const double m_snow = c.m_snow, S_abs_snow = c.S_abs_snow;
+  int rc = 0;
+  H_abs = H_abs + m_snow * latent_heat + c.H_abs_snow;
+  c.H_abs_snow = -m_snow * latent_heat;
+  H = H_abs / m;
+#define COUPLE_GETT()                                                                                      \
+  do {                                                                                                     \
+    double hs = c.H_abs_snow / m_snow;                                                                     \
+    rc |= getT(s, hs, S_abs_snow / m_snow, hs / c_l, c.T_snow, c.phi_s);                                   \
+    rc |= getT(s, H, S_bu, H / c_l, T, phi);                                                               \
+  } while (0)
+  COUPLE_GETT();
+  if (T > 0.0 && H_abs <= -c.H_abs_snow) {
+    c.H_abs_snow = c.H_abs_snow + H_abs;
+    H_abs = 0.0;
+    COUPLE_GETT();
+  } else if (T > 0.0 && H_abs > -c.H_abs_snow) {
+    H_abs = (H_abs + c.H_abs_snow) * m / m_snow / (1.0 + m / m_snow);
+    c.H_abs_snow = H_abs * m_snow / m;
+    COUPLE_GETT();
+  } else {
+    int jj = 0;
+    while (fabs(T - c.T_snow) > (double)0.1f && jj < 201) {
+      double d = c.T_snow - (c.T_snow + T) / 2.0;
+      double sg = dmax(fabs(d), 0.1);
+      if (signbit(d)) sg = -sg;
+      c.H_abs_snow = c.H_abs_snow - sg * c_s * m_snow;
+      H_abs = H_abs + sg * c_s * m_snow;
+      jj = jj + 1;
+      H = H_abs / m;
+      COUPLE_GETT();
+    }
+    if (jj > 200 && fabs(T - c.T_snow) > 1.0) rc = 16;
+  }
+#undef COUPLE_GETT
+  LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+  LAY(SAMSIM_A_T, 1) = T;
+  LAY(SAMSIM_A_PHI, 1) = phi;
+  if (rc) STOPC(rc == 16 ? 16 : 99, 1);
+}
+
+// snow_precip (mo_snow.f90:123-150) and snow_precip_0 (:167-192), called from mo_grotz.f90:251-265
+__device__ void snow_fall(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  if (!(dmax(c.liquid_precip, c.solid_precip) > 0.0)) return;
+  const double dt = g.dt, T2m = c.T2m;
+  double solid, liquid;
+  if (g.precip_flag == 0) { solid = c.solid_precip; liquid = c.liquid_precip; }
+  else if (T2m > 0.0) { solid = 0.0; liquid = c.liquid_precip; }
+  else { solid = c.liquid_precip; liquid = 0.0; }
+  if (c.Na > 1) {
+    double d_thick = dt * solid * rho_l / rho_snow;
+    c.m_snow = c.m_snow + dt * rho_l * (liquid + solid);
+    c.thick_snow = c.thick_snow + d_thick;
+    c.H_abs_snow = c.H_abs_snow + dt * T2m * liquid * rho_l * c_l;
+    c.H_abs_snow = c.H_abs_snow + dt * dmin(T2m, -1.0) * solid * rho_l * c_s;
+    c.H_abs_snow = c.H_abs_snow - dt * solid * rho_l * latent_heat;
+  } else {
+    double H_abs = LAY(SAMSIM_A_H_ABS, 1), S_abs = LAY(SAMSIM_A_S_ABS, 1);
+    const double m = LAY(SAMSIM_A_M, 1), T = LAY(SAMSIM_A_T, 1);
+    H_abs = H_abs + (liquid + solid) * (T2m - T) * dt;
+    H_abs = H_abs - solid * latent_heat * dt;
+    S_abs = S_abs - (liquid + solid) * S_abs / m * dt;
+    LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+    LAY(SAMSIM_A_S_ABS, 1) = S_abs;
+  }
+}
+
+// snow_thermo (mo_snow.f90:212-320) / snow_thermo_meltwater (:331-454) wrapped in the block of
+// mo_grotz.f90:273-292 and :604-624
+__device__ void snow_block(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  if (!(c.thick_snow > 0.0)) {
+    c.thick_snow = 0.0; c.m_snow = 0.0; c.psi_s_snow = 0.0; c.psi_l_snow = 0.0; c.psi_g_snow = 0.0;
+    c.H_abs_snow = 0.0; c.S_abs_snow = 0.0; c.melt_thick_snow = 0.0;
+    return;
+  }
+  c.melt_thick_snow = 0.0;
+  const bool meltwater = (g.snow_flush_flag == 1);
+  double m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1), H_abs = LAY(SAMSIM_A_H_ABS, 1);
+  bool touched = false;
+  double phi_snow = 0.0, max_lwc, max_lwc_v, sat_snow;
+  const double H_snow = c.H_abs_snow / c.m_snow, S_bu_snow = c.S_abs_snow / c.m_snow, psi_s_old = c.psi_s_snow;
+  const double T_in = c.T_snow;
+  int rc = getT(x.salt, H_snow, S_bu_snow, T_in, c.T_snow, phi_snow);
+  if (rc) STOPC(99, 0);
+  c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
+  c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
+  if (c.psi_s_snow + c.psi_l_snow > 1.0) {
+    c.thick_snow = c.m_snow * (phi_snow / rho_s + (1.0 - phi_snow) / rho_l);
+    c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
+    c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
+    if (fabs(c.psi_s_snow + c.psi_l_snow - 1.0) > 0.0000001) STOPC(345, 0);
+  }
+  c.psi_g_snow = 1.0 - c.psi_s_snow - c.psi_l_snow;
+  if (c.psi_s_snow > 0.0) max_lwc = 0.057 * (1.0 - c.psi_s_snow) / (c.psi_s_snow) + 0.017;
+  else max_lwc = 0.0;
+
+  if (psi_s_old > c.psi_s_snow && c.psi_s_snow > 0.0) {
+    if ((1.0 - phi_snow) > max_lwc) c.thick_snow = c.thick_snow * (1.0 - (psi_s_old - c.psi_s_snow) / psi_s_old);
+    double tmin = (phi_snow * c.m_snow / rho_s + (1.0 - phi_snow) * c.m_snow / rho_l);
+    if (c.thick_snow < tmin) c.thick_snow = tmin;
+    c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
+    c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
+    c.psi_g_snow = 1.0 - c.psi_s_snow - c.psi_l_snow;
+    c.psi_g_snow = fabs(c.psi_g_snow);
+  } else if (c.psi_s_snow < 0.000001) {
+    c.thick_snow = c.m_snow / rho_l;
+    c.psi_s_snow = 0.0; c.psi_g_snow = 0.0; c.psi_l_snow = 1.0;
+  }
+
+  const bool wet = (1.0 - phi_snow) > max_lwc && c.psi_g_snow > 0.0 && (!meltwater || c.psi_l_snow > 0.0);
+  if (wet) {
+    touched = true;
+    const double T_snow = c.T_snow, pss = c.psi_s_snow;
+    max_lwc_v = max_lwc * c.m_snow / (rho_l * c.thick_snow);
+    if (!meltwater) {
+      sat_snow = c.thick_snow * (c.psi_l_snow - max_lwc_v);
+      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, c.psi_g_snow));
+      c.thick_snow = c.thick_snow - sat_snow;
+      thick = thick + sat_snow;
+      c.m_snow = c.m_snow - sat_snow * (pss * rho_s + (1.0 - pss - gas_snow_ice2) * rho_l);
+      m = m + sat_snow * (pss * rho_s + (1.0 - pss - gas_snow_ice2) * rho_l);
+      c.H_abs_snow = c.H_abs_snow - sat_snow * pss * rho_s * c_s * T_snow;
+      H_abs = H_abs + sat_snow * pss * rho_s * c_s * T_snow;
+      c.H_abs_snow = c.H_abs_snow + sat_snow * pss * rho_s * latent_heat;
+      H_abs = H_abs - sat_snow * pss * rho_s * latent_heat;
+      c.H_abs_snow = c.H_abs_snow - sat_snow * (1.0 - pss) * rho_l * c_l * T_snow;
+      H_abs = H_abs + sat_snow * (1.0 - pss) * rho_l * c_l * T_snow;
+    } else {
+      const double ksf = g.k_snow_flush;
+      double slush = (c.psi_l_snow - max_lwc_v) * (1.0 - ksf);
+      double flush = (c.psi_l_snow - max_lwc_v) * ksf;
+      c.melt_thick_snow = c.thick_snow * flush;
+      sat_snow = c.thick_snow * (slush);
+      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, c.psi_g_snow));
+      const double gmin = dmin(gas_snow_ice2, c.psi_g_snow);
+      c.thick_snow = c.thick_snow - sat_snow - c.melt_thick_snow;
+      thick = thick + sat_snow;
+      c.m_snow = c.m_snow - sat_snow * (pss * rho_s + (1.0 - pss - gmin) * rho_l) - c.melt_thick_snow * rho_l;
+      m = m + sat_snow * (pss * rho_s + (1.0 - pss - gmin) * rho_l);
+      c.H_abs_snow = c.H_abs_snow - sat_snow * pss * rho_s * c_s * T_snow;
+      H_abs = H_abs + sat_snow * pss * rho_s * c_s * T_snow;
+      c.H_abs_snow = c.H_abs_snow + sat_snow * pss * rho_s * latent_heat;
+      H_abs = H_abs - sat_snow * pss * rho_s * latent_heat;
+      c.H_abs_snow = c.H_abs_snow - sat_snow * (1.0 - pss - gmin) * rho_l * c_l * T_snow - c.melt_thick_snow * rho_l * c_l * T_snow;
+      H_abs = H_abs + sat_snow * (1.0 - pss - gmin) * rho_l * c_l * T_snow;
+    }
+  } else if (c.psi_g_snow <= 0.0) {
+    touched = true;
+    H_abs = H_abs + c.H_abs_snow; m = m + c.m_snow; thick = thick + c.thick_snow;
+    c.H_abs_snow = 0.0; c.m_snow = 0.0; c.thick_snow = 0.0;
+    c.psi_g_snow = 0.0; c.psi_s_snow = 0.0; c.psi_l_snow = 0.0;
+  }
+  if (touched) {
+    LAY(SAMSIM_A_M, 1) = m;
+    LAY(SAMSIM_A_THICK, 1) = thick;
+    LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+  }
+  if (c.psi_g_snow < 0.0) STOPC(9876, 0);
+}
+
+// ---------------------------------------------------------------- S1: first thermodynamic sweep, bottom -> top
+// mo_grotz.f90:297-307 (S_bu, H, getT chain, S_br, Expulsion mo_thermo_functions.f90:157-187) fused with the
+// permeability / Rayleigh-number part of fl_grav_drain (mo_grav_drain.f90:103-136): ray(k) needs only suffix
+// quantities over k..N_active, which this sweep meets in the right order.
+__device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  double T_test = g.T_bottom;
+  double minp = 1.0e300, stp = 0.0, st = 0.0;  // suffix min(perm), sum(thick/perm), sum(thick) over k..Na-1
+  double S_br_bot = 0.0, bot = 0.0, botterm = 0.0, perm_bot = 0.0;
+  double min_psi_s = 1.0e300;
+  int rc = 0, rc_layer = 0;
+  if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
+  for (int k = Na; k >= 1; --k) {
+    const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), thick = LAY(SAMSIM_A_THICK, k);
+    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
+      S_abs = 0.0;
+      LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    }
+    const double S_bu = S_abs / m, H = H_abs / m;
+    double T, phi = 0.0;
+    int r = getT(s, H, S_bu, T_test, T, phi);
+    if (r && !rc) { rc = r; rc_layer = k; }
+    T_test = T;
+    const double S_br = S_br_clamped(s, T, S_bu);
+    // Expulsion
+    const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
+    double V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
+    double psi_s = V_s / thick, psi_l = (V_l - V_ex) / thick, psi_g = (thick - V_l - V_s + V_ex) / thick;
+    if (psi_l < 0.0) psi_l = 0.0;
+    if (psi_g < 0.0) psi_g = 0.0;
+    min_psi_s = dmin(min_psi_s, psi_s);
+    LAY(SAMSIM_A_T, k) = T;
+    LAY(SAMSIM_A_PHI, k) = phi;
+    LAY(SAMSIM_A_S_BU, k) = S_bu;
+    LAY(SAMSIM_A_S_BR, k) = S_br;
+    LAY(SAMSIM_A_PSI_S, k) = psi_s;
+    LAY(SAMSIM_A_PSI_L, k) = psi_l;
+    LAY(SAMSIM_A_PSI_G, k) = psi_g;
+    LAY(D_V_EX, k) = V_ex;
+    if (do_ray) {
+      const double perm = x.p17 * pow(1000.0 * fabs(psi_l), 3.10);  // mo_grav_drain.f90:105
+      if (k == Na) {
+        S_br_bot = S_br;
+        bot = thick * psi_s / psi_s_min;  // bottom layer enters linearly
+        perm_bot = perm;
+        botterm = bot / perm;
+      } else {
+        const double height = st + bot;  // thick(k+1..Na-1) + bottom part
+        minp = dmin(minp, perm);
+        stp = stp + thick / perm;
+        st = st + thick;
+        double ray;
+        const double d_S_br = S_br - S_br_bot;
+        if (g.harmonic_flag == 2) {
+          double hp = (minp < x.p14) ? 0.0 : (st + bot) / (stp + botterm);
+          ray = grav_f * rho_l * bbeta * d_S_br * height * hp;
+        } else {
+          ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(minp, perm_bot);
+        }
+        ray = ray / (kappa_l * mu);
+        ray = dmax(ray, 0.0);
+        LAY(SAMSIM_A_RAY, k) = ray;
+      }
+    }
+  }
+  c.min_psi_s = min_psi_s;
+  if (rc) STOPC(rc, rc_layer);
+}
+
+// ---------------------------------------------------------------- P2: expulsion_flux + mass_transfer, top -> bottom
+// expulsion_flux (mo_mass.f90:112-136): downward brine flux recurrence, m and psi_g update.  mass_transfer
+// (mo_mass.f90:53-96) with these fluxes (all <= 0: brine only moves down) needs the layer above only.  Then the
+// S_bu refresh of mo_grotz.f90:333-335.  mass_transfer is skipped on the first step (mo_grotz.f90:313).
+__device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const bool transfer = (c.step + 1 != 1);
+  double flm_k = 0.0;  // fl_m(k)
+  double T_up = 0.0, S_bu_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, snapshot S_bu, UPDATED S_abs
+  for (int k = 1; k <= Na; ++k) {
+    const double V_ex = LAY(D_V_EX, k);
+    double m = LAY(SAMSIM_A_M, k);
+    double flm_next;
+    if (k == 1) {
+      flm_next = -V_ex * rho_l;
+    } else {
+      double psi_g = LAY(SAMSIM_A_PSI_G, k);
+      if (psi_g < (double)0.001f) {
+        flm_next = -V_ex * rho_l + flm_k;
+      } else {
+        const double thick = LAY(SAMSIM_A_THICK, k);
+        flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
+        psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
+        LAY(SAMSIM_A_PSI_G, k) = psi_g;
+      }
+    }
+    m = m + flm_next - flm_k;
+    LAY(SAMSIM_A_M, k) = m;
+    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const double T = LAY(SAMSIM_A_T, k), S_bu = LAY(SAMSIM_A_S_BU, k);
+    if (transfer) {
+      double H_abs = LAY(SAMSIM_A_H_ABS, k);
+      bool ch = false;
+      if (flm_next < 0.0) {
+        H_abs = H_abs + flm_next * T * c_l;
+        S_abs = S_abs + dmax(flm_next * S_br_clamped(s, T, S_bu), -S_abs);
+        ch = true;
+      }
+      if (flm_k < 0.0) {
+        H_abs = H_abs - flm_k * T_up * c_l;
+        S_abs = S_abs - dmax(flm_k * S_br_clamped(s, T_up, S_bu_up), -S_abs_up);
+        ch = true;
+      }
+      if (ch) {
+        LAY(SAMSIM_A_H_ABS, k) = H_abs;
+        LAY(SAMSIM_A_S_ABS, k) = S_abs;
+      }
+    }
+    LAY(SAMSIM_A_S_BU, k) = S_abs / m;
+    T_up = T; S_bu_up = S_bu; S_abs_up = S_abs;
+    flm_k = flm_next;
+  }
+}
+
+// ---------------------------------------------------------------- vital signs, mo_grotz.f90:192-223 (output only)
+__device__ void vital_signs(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  double sH = 0.0, sm = 0.0, sS = 0.0, resist = 0.0, sth = 0.0, sS1 = 0.0, sm1 = 0.0;
+  for (int k = 1; k <= Na; ++k) {
+    const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+    sH += H_abs; sm += m; sS += S_abs;
+    if (k <= Na - 1) {
+      const double thick = LAY(SAMSIM_A_THICK, k);
+      resist = resist + thick / (LAY(SAMSIM_A_PSI_L, k) * k_l + LAY(SAMSIM_A_PSI_S, k) * k_s);
+      sth += thick; sS1 += S_abs; sm1 += m;
+    }
+  }
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  c.energy_stored = c.H_abs_snow + sH - g.T_bottom * sm * c_l;
+  c.freshwater = sm / rho_l;
+  c.freshwater = c.freshwater * (1.0 - sS / sm / ref_salinity);
+  c.freshwater = c.freshwater + c.m_snow / rho_l;
+  resist = resist + thN * psN / psi_s_min * (psi_s_min * k_s + 1.0 - psi_s_min * k_l);
+  if (c.thick_snow > g.thick_min / 110.0) resist = resist + c.thick_snow / func_k_snow(c.m_snow, c.thick_snow);
+  c.total_resist = resist;
+  c.thickness = ((Na > 1) ? sth : 0.0) + thN * psN / psi_s_min;
+  if (Na > 1) {
+    const double SN = LAY(SAMSIM_A_S_ABS, Na), mN = LAY(SAMSIM_A_M, Na);
+    c.bulk_salin = (sS1 + SN * psN / psi_s_min) / (sm1 + mN * psN / psi_s_min);
+  } else {
+    c.bulk_salin = LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1);
+  }
+}
+
+// ---------------------------------------------------------------- flood, mo_flood.f90:55-151
+__device__ void flood(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  double hp = 0.0, sth = 0.0;
+  for (int k = 1; k <= Na - 1; ++k) {
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    const double perm = x.p17 * pow(1000.0 * LAY(SAMSIM_A_PSI_L, k), 3.10);
+    hp = hp + thick / perm;
+    sth += thick;
+  }
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  const double permN = x.p17 * pow(1000.0 * LAY(SAMSIM_A_PSI_L, Na), 3.10);
+  hp = hp + (thN * psN / psi_s_min) / permN;
+  hp = (sth + thN * psN / psi_s_min) / hp;
+  const double sall = sth + thN;
+  const double freeboard = c.freeboard, psi_g_snow = c.psi_g_snow;
+  double flood_brine = -g.dt * grav_f * rho_l * rho_l * hp * (freeboard) / (mu * sall);
+  const double shift_ice = flood_brine / (rho_l * psi_g_snow / ratio_flood);
+  const double shift_snow = shift_ice * (1 + psi_g_snow / (1.0 - psi_g_snow) * (1.0 - 1.0 / ratio_flood));
+
+  double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
+  double SN = LAY(SAMSIM_A_S_ABS, Na), HN = LAY(SAMSIM_A_H_ABS, Na);
+  const double mN = LAY(SAMSIM_A_M, Na), TN = LAY(SAMSIM_A_T, Na);
+  const double S_buN = SN / mN;
+
+  S1 = S1 + flood_brine * S_buN;
+  H1 = H1 + flood_brine * HN / mN;
+  m1 = m1 + flood_brine;
+  th1 = th1 + shift_ice;
+  H1 = H1 + shift_snow / c.thick_snow * c.H_abs_snow;
+  c.H_abs_snow = c.H_abs_snow - shift_snow / c.thick_snow * c.H_abs_snow;
+  m1 = m1 + shift_snow / c.thick_snow * c.m_snow;
+  c.m_snow = c.m_snow - shift_snow / c.thick_snow * c.m_snow;
+  c.thick_snow = c.thick_snow - shift_snow;
+
+  if (freeboard + shift_ice < neg_free) {
+    const double shift = neg_free - (freeboard + shift_ice);
+    flood_brine = shift * (psi_g_snow) * rho_l;
+    SN = SN + (g.S_bu_bottom - S_buN) * flood_brine;
+    HN = HN + (g.T_bottom - TN) * c_l * flood_brine;
+    S1 = S1 + S_buN * flood_brine;
+    H1 = H1 + TN * c_l * flood_brine;
+    m1 = m1 + flood_brine;
+    th1 = th1 + shift;
+    H1 = H1 + shift / c.thick_snow * c.H_abs_snow;
+    c.H_abs_snow = c.H_abs_snow - shift / c.thick_snow * c.H_abs_snow;
+    m1 = m1 + shift / c.thick_snow * c.m_snow;
+    c.m_snow = c.m_snow - shift / c.thick_snow * c.m_snow;
+    c.thick_snow = c.thick_snow - shift;
+    LAY(SAMSIM_A_S_ABS, Na) = SN;
+    LAY(SAMSIM_A_H_ABS, Na) = HN;
+  }
+  LAY(SAMSIM_A_S_ABS, 1) = S1;
+  LAY(SAMSIM_A_H_ABS, 1) = H1;
+  LAY(SAMSIM_A_M, 1) = m1;
+  LAY(SAMSIM_A_THICK, 1) = th1;
+}
+
+// recompute ray(1) after flood changed thick(1) (thick(1) enters only the k = 1 harmonic mean)
+__device__ void refresh_ray_top(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  if (g.harmonic_flag != 2) return;  // MINVAL variant does not depend on thick(1)
+  double minp = 1.0e300, stp = 0.0, st = 0.0, height = 0.0;
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  const double bot = thN * psN / psi_s_min;
+  const double botterm = bot / (x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, Na)), 3.10));
+  for (int k = Na - 1; k >= 1; --k) {
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    const double perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)), 3.10);
+    height = st + bot;
+    minp = dmin(minp, perm);
+    stp = stp + thick / perm;
+    st = st + thick;
+  }
+  double hp = (minp < x.p14) ? 0.0 : (st + bot) / (stp + botterm);
+  double ray = grav_f * rho_l * bbeta * (LAY(SAMSIM_A_S_BR, 1) - LAY(SAMSIM_A_S_BR, Na)) * height * hp;
+  ray = ray / (kappa_l * mu);
+  LAY(SAMSIM_A_RAY, 1) = dmax(ray, 0.0);
+}
+
+// ---------------------------------------------------------------- P3: gravity drainage, top -> bottom
+// fl_grav_drain (mo_grav_drain.f90:138-200) with ray(k) from S1: drainage flux of layer k leaves straight to the
+// ocean, the compensating upward flow fl_up passes through every layer below (running sum), then mass_transfer
+// (mo_mass.f90:53-96) with fl_m(k+1) = fl_up(k) >= 0.  mass_transfer reads the salt of the layer BELOW after the
+// drainage loop (snapshot SS_abs), so layer k+1 is drained one iteration ahead of the transfer into layer k.
+// The same pass multiplies up the Beer-law transmittance for fl_rad(N_active) (mo_heat_fluxes.f90:151-155).
+__device__ void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer0) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const double dt = g.dt;
+  double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300;
+  // Beer law: temp2 decays layer by layer; exp() is re-evaluated only when the thickness changes
+  double temp2 = beer0, e = 0.0, th_prev = -1.0;
+  int stop_layer = 0;
+
+  struct L { double T, S_bu, S_abs, H_abs, flup; bool ch; };
+  double S_br_j = LAY(SAMSIM_A_S_BR, 1);  // S_br(j), prefetched one layer ahead
+
+  // drain(j): gravity-drainage loss of layer j (mo_grav_drain.f90:144-170) and fl_up(j)
+  auto drain = [&](int j) -> L {
+    L r;
+    r.T = LAY(SAMSIM_A_T, j);
+    r.S_bu = LAY(SAMSIM_A_S_BU, j);
+    r.S_abs = LAY(SAMSIM_A_S_ABS, j);
+    r.H_abs = LAY(SAMSIM_A_H_ABS, j);
+    r.ch = false;
+    const double thick = LAY(SAMSIM_A_THICK, j);
+    if (do_beer) {
+      if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
+      if (j == Na) c.frad = temp2 - temp2 * e;
+      temp2 = temp2 * e;
+    }
+    sum_before += r.S_abs;
+    r.flup = cum;
+    if (j <= Na - 1) {
+      const double S_br = S_br_j;
+      S_br_j = LAY(SAMSIM_A_S_BR, j + 1);
+      const double ray = LAY(SAMSIM_A_RAY, j);
+      if (ray > ray_crit && S_br > S_br_j) {
+        const double psi_s = LAY(SAMSIM_A_PSI_S, j), m = LAY(SAMSIM_A_M, j);
+        if (psi_s > 0.001 && r.S_abs / m > 0.1) {
+          const double psi_l = LAY(SAMSIM_A_PSI_L, j);
+          double flux = x_grav * (ray - ray_crit) * dt * thick;
+          flux = dmin(flux, psi_l * rho_l * thick);
+          r.S_abs = r.S_abs - flux * S_br;
+          if (r.S_abs < 0.0 && !stop_layer) stop_layer = j;
+          c.grav_temp = c.grav_temp + flux * r.T;
+          r.H_abs = r.H_abs - flux * c_l * r.T;
+          heat_loss = heat_loss + flux * c_l * r.T;
+          cum = cum + flux;
+          r.flup = dmin(cum, psi_l * rho_l * thick);
+          r.ch = true;
+        }
+      }
+    }
+    sum_after += r.S_abs;
+    return r;
+  };
+
+  L cur = drain(1), nxt = cur;
+  double flup_prev = 0.0;  // fl_up(k-1) = fl_m(k)
+  for (int k = 1; k <= Na; ++k) {
+    double T_below, S_bu_below, SS_abs_below;
+    if (k < Na) {
+      nxt = drain(k + 1);
+      T_below = nxt.T; S_bu_below = nxt.S_bu; SS_abs_below = nxt.S_abs;
+    } else {
+      T_below = g.T_bottom; S_bu_below = g.S_bu_bottom; SS_abs_below = g.S_bu_bottom * 2000.0;
+    }
+    if (cur.flup > 0.0) {  // fl_m(k+1) > 0: inflow from below
+      cur.H_abs = cur.H_abs + cur.flup * T_below * c_l;
+      cur.S_abs = cur.S_abs + dmin(cur.flup * S_br_clamped(s, T_below, S_bu_below), SS_abs_below);
+      cur.ch = true;
+    }
+    if (flup_prev > 0.0) {  // fl_m(k) > 0: outflow to the layer above
+      cur.H_abs = cur.H_abs - flup_prev * cur.T * c_l;
+      cur.S_abs = cur.S_abs - dmin(flup_prev * S_br_clamped(s, cur.T, cur.S_bu), cur.S_abs);
+      cur.ch = true;
+    }
+    if (k == Na) {
+      c.grav_drain = c.grav_drain + cur.flup;
+      if (g.grav_heat_flag == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
+    }
+    if (cur.ch) {
+      LAY(SAMSIM_A_S_ABS, k) = cur.S_abs;
+      LAY(SAMSIM_A_H_ABS, k) = cur.H_abs;
+    }
+    minS = dmin(minS, cur.S_abs);
+    flup_prev = cur.flup;
+    cur = nxt;
+  }
+  c.grav_salt = c.grav_salt + sum_before;
+  c.grav_salt = c.grav_salt - sum_after;
+  if (stop_layer) STOPC(21234, stop_layer);
+  if (minS < 0.0) STOPC(1337, 0);
+}
+
+// Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
+__device__ void sweep_beer(Col &c, double beer0) {
+  const int Na = c.Na;
+  double temp2 = beer0, e = 0.0, th_prev = -1.0;
+  for (int k = 1; k <= Na; ++k) {
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
+    if (k == Na) c.frad = temp2 - temp2 * e;
+    temp2 = temp2 * e;
+  }
+}
+
+// ---------------------------------------------------------------- surface energy balance, mo_heat_fluxes.f90:77-195
+// sets fl_Q(1), T_top, fl_Q_snow, albedo, fl_sw, fl_lw, T_freeze; returns the Beer-law surface value temp2
+__device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
+  const samsim_config &g = x.p->cfg;
+  if (g.boundflux_flag != 2) return 0.0;
+  const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1);
+  c.albedo = func_albedo(c.thick_snow, c.T_snow, psi_l1, g.thick_min, g.albedo_flag);
+  const DevParams *p = x.p;
+  if (time == time_input(tc)) {
+    c.fl_sw = p->f_sw[tc - 1];
+    c.fl_lw = p->f_lw[tc - 1];
+  } else {
+    const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
+    c.fl_sw = (1.0 - temp) * p->f_sw[tc - 2] + temp * p->f_sw[tc - 1];
+    c.fl_lw = (1.0 - temp) * p->f_lw[tc - 2] + temp * p->f_lw[tc - 1];
+  }
+  const double pen = (c.thick_snow < g.thick_min) ? penetr : 0.0;
+  return pen * (1.0 - c.albedo) * c.fl_sw;
+}
+
+__device__ void surface_flux(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
+  const double thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
+  const double k1 = psi_s1 * k_s + psi_l1 * k_l + psi_g1 * 0.0;
+  if (g.boundflux_flag == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
+    double fl = (T1 - c.T_top) / (thick1 / (2.0 * k1));
+    if (fabs(fl) > g.max_flux_plate) fl = fl / fabs(fl) * g.max_flux_plate;
+    c.fl_Q1 = fl;
+    return;
+  }
+  // boundflux_flag 2, mo_heat_fluxes.f90:91-195
+  const double thick_min = g.thick_min;
+  const double fl_rest = c.fl_lw + 0.0 + 0.0;
+  double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
+  const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
+  const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
+  T_old = T_old + zeroK;
+  double temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
+  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 - zeroK;
+  T_old = temp1 + zeroK;
+  temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
+  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 - zeroK;
+  c.T_top = temp1;
+
+  if (c.thick_snow >= thick_min / 100.0) c.T_freeze = 0.0;
+  else c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
+
+  const double k_snow = (c.thick_snow >= thick_min / 100.0) ? func_k_snow(c.m_snow, c.thick_snow) : 0.0;
+  // sub_fl_Q_snow, mo_snow.f90:498-518
+  const double flq_snow_ice = (T1 - c.T_snow) / (c.thick_snow / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
+  if (c.T_top > c.T_freeze && Na > 1) {
+    temp1 = emi * sigma * pow(c.T_freeze + zeroK, 4.0) - (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw - fl_rest;
+    if (c.thick_snow >= thick_min) { c.fl_Q_snow = temp1; c.fl_Q1 = flq_snow_ice; }
+    else if (c.thick_snow >= thick_min / 100.0) { c.fl_Q_snow = temp1; c.fl_Q1 = 0.0; }
+    else c.fl_Q1 = temp1;
+    c.T_top = c.T_freeze;
+  } else {
+    if (c.thick_snow >= thick_min) {
+      c.fl_Q1 = flq_snow_ice;
+      c.fl_Q_snow = (c.T_snow - c.T_top) / (c.thick_snow / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
+    } else if (c.thick_snow > thick_min / 100.0 && c.thick_snow < thick_min) {
+      c.fl_Q1 = 0.0;
+      // sub_fl_Q_0_snow_thin, mo_snow.f90:466-487
+      double k = c.thick_snow / (c.thick_snow + thick1) * k_snow + thick1 / (c.thick_snow + thick1) * k1;
+      c.fl_Q_snow = (c.T_snow - c.T_top) / ((c.thick_snow + thick1) / (2.0 * k));
+    } else {
+      c.fl_Q1 = (T1 - c.T_top) / (thick1 / (2.0 * k1));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- P4: heat + second thermodynamic sweep, bottom -> top
+// mo_heat_fluxes.f90:262-310 (stencil fl_Q(k) = (T_k - T_{k-1}) / (thick_{k-1}/2k_{k-1} + thick_k/2k_k), explicit
+// H_abs update, fl_rad(N_active) added to EVERY layer, snow enthalpy, energy assert) fused with the getT sweep
+// of mo_grotz.f90:592-598: fl_Q(k) only needs the OLD temperatures of k-1 and k, so the freshly updated H_abs(k)
+// feeds the Newton chain directly.
+__device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const double dt = g.dt, thick_min = g.thick_min;
+  const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
+  const double H_abs_snow_before = c.H_abs_snow;
+  double sum_before = 0.0, sum_after = 0.0;
+  double flq_below = c.fl_q_bottom;  // fl_Q(k+1)
+  double T_test = g.T_bottom;
+  int rc = 0, rc_layer = 0;
+  // layer k (old values)
+  double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
+  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l + LAY(SAMSIM_A_PSI_G, Na) * 0.0;
+  for (int k = Na; k >= 1; --k) {
+    double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
+    if (k > 1) {
+      T_u = LAY(SAMSIM_A_T, k - 1);
+      th_u = LAY(SAMSIM_A_THICK, k - 1);
+      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l + LAY(SAMSIM_A_PSI_G, k - 1) * 0.0;
+      const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
+      flq_k = (T_k - T_u) / R;
+    } else {
+      flq_k = c.fl_Q1;
+    }
+    double H_abs = LAY(SAMSIM_A_H_ABS, k);
+    sum_before += H_abs;
+    H_abs = H_abs + (flq_below - flq_k) * dt;
+    H_abs = H_abs + c.frad * dt;
+    const double m = LAY(SAMSIM_A_M, k);
+    if (k == 1) {  // snow treatment, mo_heat_fluxes.f90:291-303
+      if (thin_snow) {
+        c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
+        LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+        snow_coupling(c, x);
+        if (c.status) return;
+        H_abs = LAY(SAMSIM_A_H_ABS, 1);
+      } else if (c.thick_snow >= thick_min) {
+        c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
+      }
+    }
+    sum_after += H_abs;
+    LAY(SAMSIM_A_H_ABS, k) = H_abs;
+    const double S_bu = LAY(SAMSIM_A_S_ABS, k) / m, H = H_abs / m;
+    double T, phi = 0.0;
+    int r = getT(s, H, S_bu, T_test, T, phi);
+    if (r && !rc) { rc = r; rc_layer = k; }
+    T_test = T;
+    LAY(SAMSIM_A_T, k) = T;
+    LAY(SAMSIM_A_PHI, k) = phi;
+    LAY(SAMSIM_A_S_BU, k) = S_bu;
+    flq_below = flq_k;
+    T_k = T_u; th_k = th_u; kk_k = kk_u;
+  }
+  // energy conservation assert, mo_heat_fluxes.f90:265-310
+  double temp1 = sum_before + H_abs_snow_before;
+  temp1 = temp1 + (double)Na * (c.frad * dt);
+  if (thin_snow || c.thick_snow >= thick_min) temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
+  else temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q1 * dt;
+  const double temp2 = sum_after + c.H_abs_snow;
+  if (rc) STOPC(rc, rc_layer);
+  if (fabs((temp1 - temp2) / dt) > 0.00001) STOPC(431, 0);
+}
+
+// ---------------------------------------------------------------- melt film, mo_functions.f90:386-474
+__device__ void sub_melt_thick(double psi_l, double psi_s, double psi_g, double T, double T_freeze, double T_top, double fl_Q,
+                               double thick_snow, double dt, double &melt_thick, double &thick, double thick_min) {
+  melt_thick = 0.0;
+  if (thick_snow < thick_min && T_top >= T_freeze) {
+    melt_thick = -fl_Q - 2.0 * (psi_l * k_l + psi_s * k_s) / thick * (T_freeze - T);
+    melt_thick = melt_thick * dt / dmax(latent_heat * rho_s * psi_s, 0.000000000000001);
+    melt_thick = dmin(psi_l * thick, melt_thick);
+  }
+  if (psi_s < psi_s_top_min) melt_thick = thick * (1.0 - psi_s / psi_s_top_min);
+  if (melt_thick > 0.0 && psi_g > gas_snow_ice2) {
+    if (melt_thick > (psi_g - gas_snow_ice2) * thick) {
+      melt_thick = melt_thick - (psi_g - gas_snow_ice2) * thick;
+      thick = thick * (1.0 - (psi_g - gas_snow_ice2));
+    } else {
+      thick = thick - melt_thick;
+      melt_thick = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- flush3, mo_flush.f90:70-237
+__device__ void flush3(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na, N = c.N;
+  const double dt = g.dt;
+  // horizontal flow length = total thickness (mo_flush.f90:104)
+  double cnst = 0.0;
+  for (int k = 1; k <= Na; ++k) cnst += LAY(SAMSIM_A_THICK, k);
+  cnst = cnst * para_flush_horiz;
+  const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
+  c.melt_thick = dmin(c.melt_thick, psi_l1 * thick1);
+  c.melt_thick = dmin(c.melt_thick, g.thick_0 / 3.0);
+
+  // permeability and bottom -> top equivalent resistance R(k) (stored in the V_ex scratch rows)
+  const double pfill = (g.snow_flush_flag == 1) ? 0.0 : 1.0;
+  for (int k = Na + 1; k <= N; ++k) LAY(SAMSIM_A_PERM, k) = pfill;
+  double R_below = 0.0;  // R(k+1)
+  for (int k = Na; k >= 1; --k) {
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    double perm;
+    if (g.snow_flush_flag == 1) {
+      perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k) + 2.0 * LAY(SAMSIM_A_PSI_G, k)), 3.10);
+      if (perm == 0.0) perm = 1.0;
+    } else {
+      perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)), 3.10);
+    }
+    LAY(SAMSIM_A_PERM, k) = perm;
+    const double pm = dmax(perm, 0.00000000000000000000001);
+    const double R_v = mu * thick / pm, R_h = mu * cnst / (thick * pm);
+    double R;
+    if (k == Na) R = 0.0;
+    else if (k == Na - 1) R = R_v;
+    else { R = R_below + R_v; R = ((R)*R_h) / (R + R_h); }
+    LAY(D_V_EX, k) = R;
+    R_below = R;
+  }
+  const double R1 = R_below;
+  double flush_total = (c.freeboard + c.melt_thick) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
+  flush_total = dmin(flush_total, c.melt_thick * rho_l);
+  c.melt_err = c.melt_err + c.melt_thick - dmin(flush_total / rho_l, c.melt_thick);
+
+  // top -> bottom: split into vertical / horizontal parts, vertical mass_transfer (fl_m(k+1) = -flush_v(k) <= 0),
+  // horizontal loss of every layer goes to layer N_active
+  double fv_up = 0.0;                                  // flush_v(k-1)
+  double T_up = 0.0, S_bu_up = 0.0, S_abs_up = 0.0;    // layer k-1: T, local S_bu snapshot, S_abs after the vertical transfer
+  double sum_fh = 0.0, accH = 0.0, accS = 0.0, minS = 1.0e300;
+  double S_bu_N = 0.0;
+  for (int k = 1; k <= Na; ++k) {
+    const double thick = LAY(SAMSIM_A_THICK, k), perm = LAY(SAMSIM_A_PERM, k), T = LAY(SAMSIM_A_T, k);
+    double m = LAY(SAMSIM_A_M, k), S_abs = LAY(SAMSIM_A_S_ABS, k), H_abs = LAY(SAMSIM_A_H_ABS, k);
+    const double S_bu = S_abs / m;  // local S_bu of flush3 (mo_flush.f90:101)
+    const double pm = dmax(perm, 0.00000000000000000000001);
+    const double R_v = mu * thick / pm, R_h = mu * cnst / (thick * pm);
+    double fh, fv;
+    if (k <= Na - 1) {
+      const double Rn = LAY(D_V_EX, k + 1);
+      const double src = (k == 1) ? flush_total : fv_up;
+      fh = src * (Rn + R_v) / (Rn + R_v + R_h);
+      fv = src * R_h / (Rn + R_v + R_h);
+    } else {
+      fv = fv_up;
+      fh = 0.0;
+    }
+    LAY(SAMSIM_A_FLUSH_V, k) = LAY(SAMSIM_A_FLUSH_V, k) + fv;  // accumulated output, mo_grotz.f90:697-737
+    LAY(SAMSIM_A_FLUSH_H, k) = LAY(SAMSIM_A_FLUSH_H, k) + fh;
+    sum_fh += fh;
+    const double flm_next = -fv, flm_k = -fv_up;
+    if (flm_next < 0.0) {
+      H_abs = H_abs + flm_next * T * c_l;
+      S_abs = S_abs + dmax(flm_next * S_br_clamped(s, T, S_bu), -S_abs);
+    }
+    if (k > 1 && flm_k < 0.0) {
+      H_abs = H_abs - flm_k * T_up * c_l;
+      S_abs = S_abs - dmax(flm_k * S_br_clamped(s, T_up, S_bu_up), -S_abs_up);
+    }
+    T_up = T; S_bu_up = S_bu; S_abs_up = S_abs;
+    fv_up = fv;
+    if (k == Na) {
+      S_bu_N = S_bu;
+      if (g.flush_heat_flag == 2) H_abs = H_abs - flm_next * T * c_l;
+      // horizontal contributions of the layers above, then the loss of all horizontal brine
+      H_abs = H_abs + accH;
+      S_abs = S_abs + accS;
+      const double loss_S = sum_fh * S_bu_N, loss_H = sum_fh * T * c_l;
+      if (g.flush_heat_flag == 2) H_abs = H_abs - loss_H;
+      S_abs = S_abs - loss_S;
+    } else {
+      if (k == 1) {
+        m = m - flush_total;
+        LAY(SAMSIM_A_M, 1) = m;
+        LAY(SAMSIM_A_THICK, 1) = thick - flush_total / rho_l;
+      }
+      const double loss_S = fh * S_br_clamped(s, T, S_abs / m);
+      const double loss_H = fh * T * c_l;
+      S_abs = S_abs - loss_S;
+      H_abs = H_abs - loss_H;
+      accH += loss_H;
+      accS += loss_S;
+    }
+    LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    LAY(SAMSIM_A_H_ABS, k) = H_abs;
+    minS = dmin(minS, S_abs);
+  }
+  if (minS < -0.00000000000000000000000001) {
+    for (int k = 1; k <= Na; ++k) {
+      const double v = LAY(SAMSIM_A_S_ABS, k);
+      if (v < 0.0) LAY(SAMSIM_A_S_ABS, k) = 0.0;
+    }
+  }
+  if (fabs(LAY(SAMSIM_A_M, 1)) < 0.000001) STOPC(9876, 1);
+}
+
+// ---------------------------------------------------------------- layer_dynamics, mo_layer_dynamics.f90:64-716
+struct LayerVals { double rho, S_bu, H; };
+__device__ __forceinline__ LayerVals layer_vals(Col &c, int k) {
+  const double m = LAY(SAMSIM_A_M, k);
+  LayerVals v;
+  v.rho = m / LAY(SAMSIM_A_THICK, k);
+  v.S_bu = LAY(SAMSIM_A_S_ABS, k) / m;
+  v.H = LAY(SAMSIM_A_H_ABS, k) / m;
+  return v;
+}
+__device__ __forceinline__ void set_layer(Col &c, int k, const LayerVals &v, double thick_0) {
+  LAY(SAMSIM_A_M, k) = v.rho * thick_0;
+  LAY(SAMSIM_A_S_ABS, k) = v.S_bu * v.rho * thick_0;
+  LAY(SAMSIM_A_H_ABS, k) = v.H * v.rho * thick_0;
+}
+__device__ __forceinline__ void zero_layer(Col &c, int k) {
+  LAY(SAMSIM_A_M, k) = 0.0; LAY(SAMSIM_A_S_ABS, k) = 0.0; LAY(SAMSIM_A_H_ABS, k) = 0.0; LAY(SAMSIM_A_THICK, k) = 0.0;
+}
+
+// top_melt, mo_layer_dynamics.f90:191-327
+__device__ void top_melt(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
+  const double thick_0 = g.thick_0;
+  int Na = c.Na;
+  // layer 1 absorbs layer 2
+  LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) + LAY(SAMSIM_A_M, 2);
+  LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) + LAY(SAMSIM_A_S_ABS, 2);
+  LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) + LAY(SAMSIM_A_H_ABS, 2);
+  LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + LAY(SAMSIM_A_THICK, 2);
+  // the layer values that later branches need from the OLD profile
+  const bool have_mid = (Na == N);
+  LayerVals old_top1 = {0, 0, 0};
+  if (have_mid) old_top1 = layer_vals(c, N_top + 1);
+  const int kend = (N_top - 1 < Na - 1) ? N_top - 1 : Na - 1;
+  for (int k = 2; k <= kend; ++k) set_layer(c, k, layer_vals(c, k + 1), thick_0);  // reads old k+1 (not yet modified)
+  if (Na <= N_top) {
+    zero_layer(c, Na);
+    Na = Na - 1;
+  } else if (Na > N_top && Na <= N && LAY(SAMSIM_A_THICK, N_top + 1) / thick_0 < 1.00001) {
+    for (int k = N_top; k <= Na - 1; ++k) set_layer(c, k, layer_vals(c, k + 1), thick_0);
+    zero_layer(c, Na);
+    Na = Na - 1;
+  }
+  if (Na == N && LAY(SAMSIM_A_THICK, N_top + 1) - thick_0 >= 0.000001) {
+    double loss_m = thick_0 * old_top1.rho, loss_S = loss_m * old_top1.S_bu, loss_H = loss_m * old_top1.H;
+    LAY(SAMSIM_A_M, N_top) = loss_m; LAY(SAMSIM_A_S_ABS, N_top) = loss_S; LAY(SAMSIM_A_H_ABS, N_top) = loss_H;
+    for (int k = N_top + 1; k <= N_middle + N_top; ++k) {
+      const LayerVals below = layer_vals(c, k + 1);  // old values of k+1
+      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+      m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
+      const double shift = thick_0 * (double)(float)(N_middle - k + N_top) / (double)(float)(N_middle);
+      loss_m = shift * below.rho; loss_S = loss_m * below.S_bu; loss_H = loss_m * below.H;
+      m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
+      LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    }
+    for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thick_0 / (double)(float)(N_middle);
+  }
+  c.Na = Na;
+  double sth = 0.0;
+  for (int k = 1; k <= N; ++k) sth += LAY(SAMSIM_A_THICK, k);
+  if (thick_0 * (Na + 0.501) <= sth && Na < N) STOPC(7889, 0);
+}
+
+// top_grow, mo_layer_dynamics.f90:607-716
+__device__ void top_grow(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
+  const double thick_0 = g.thick_0;
+  int Na = c.Na;
+  LayerVals carry = layer_vals(c, 1);  // old values of layer k-1
+  {
+    const double loss_m = thick_0 * carry.rho, loss_S = loss_m * carry.S_bu, loss_H = loss_m * carry.H;
+    LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) - loss_m;
+    LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) - loss_S;
+    LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - loss_H;
+    LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - thick_0;
+  }
+  int kend = (N_top < Na) ? N_top : Na;
+  if (Na > N_top && Na < N) kend = Na;  // second branch continues the same shift over N_top+1..Na
+  for (int k = 2; k <= kend; ++k) {
+    const LayerVals old_k = layer_vals(c, k);
+    set_layer(c, k, carry, thick_0);
+    carry = old_k;
+  }
+  if (Na <= N_top || (Na > N_top && Na < N)) {
+    Na = Na + 1;
+    set_layer(c, Na, carry, thick_0);  // S_bu*thick_0*rho and S_bu*rho*thick_0 differ in association:
+    LAY(SAMSIM_A_S_ABS, Na) = carry.S_bu * thick_0 * carry.rho;  // mo_layer_dynamics.f90:660-661,674-675
+    LAY(SAMSIM_A_H_ABS, Na) = carry.H * thick_0 * carry.rho;
+    LAY(SAMSIM_A_THICK, Na) = thick_0;
+  } else if (Na == N) {
+    // carry holds the old values of layer N_top
+    double loss_m = thick_0 * carry.rho, loss_S = loss_m * carry.S_bu, loss_H = loss_m * carry.H;
+    for (int k = N_top + 1; k <= N_middle + N_top; ++k) {
+      const LayerVals own = layer_vals(c, k);  // old values of k
+      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+      m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
+      const double shift = thick_0 * (double)(float)(N_middle - k + N_top) / (double)(float)(N_middle);
+      loss_m = shift * own.rho; loss_S = loss_m * own.S_bu; loss_H = loss_m * own.H;
+      m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
+      LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    }
+    for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thick_0 / (double)(float)(N_middle);
+  }
+  c.Na = Na;
+}
+
+// bottom_melt, mo_layer_dynamics.f90:341-427 (N_active == Nlayer)
+__device__ void bottom_melt(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
+  const double thN = LAY(SAMSIM_A_THICK, N);
+  double loss_m = 0.0, loss_S = 0.0, loss_H = 0.0;
+  LayerVals carry = {0, 0, 0};
+  for (int k = N_top + 1; k <= N_top + N_middle; ++k) {
+    const LayerVals own = layer_vals(c, k);
+    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+    m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
+    const double shift = thN * (k - N_top) / (double)(float)(N_middle);
+    loss_m = shift * own.rho; loss_H = loss_m * own.H; loss_S = loss_m * own.S_bu;
+    m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
+    LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thN / (double)(float)(N_middle);
+    carry = own;
+  }
+  for (int k = N_top + N_middle + 1; k <= N; ++k) {
+    const LayerVals own = layer_vals(c, k);
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    LAY(SAMSIM_A_H_ABS, k) = carry.rho * thick * carry.H;
+    LAY(SAMSIM_A_S_ABS, k) = carry.rho * thick * carry.S_bu;
+    LAY(SAMSIM_A_M, k) = carry.rho * thick;
+    carry = own;
+  }
+}
+
+// bottom_growth, mo_layer_dynamics.f90:438-523 (N_active == Nlayer)
+__device__ void bottom_growth(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, N_top = g.n_top, N_middle = g.n_middle, N_bottom = g.n_bottom;
+  const double thN = LAY(SAMSIM_A_THICK, N);
+  double gain_m = 0.0, gain_S = 0.0, gain_H = 0.0;
+  for (int k = N_top + 1; k <= N_top + N_middle; ++k) {
+    const LayerVals below = layer_vals(c, k + 1);
+    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+    m = m - gain_m; H_abs = H_abs - gain_H; S_abs = S_abs - gain_S;
+    const double shift = thN * (k - N_top) / (double)(float)(N_middle);
+    gain_m = shift * below.rho; gain_H = gain_m * below.H; gain_S = gain_m * below.S_bu;
+    m = m + gain_m; H_abs = H_abs + gain_H; S_abs = S_abs + gain_S;
+    LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+  }
+  for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thN / (double)(float)(N_middle);
+  for (int k = N - N_bottom + 1; k <= N - 1; ++k) {
+    LAY(SAMSIM_A_H_ABS, k) = LAY(SAMSIM_A_H_ABS, k + 1);
+    LAY(SAMSIM_A_S_ABS, k) = LAY(SAMSIM_A_S_ABS, k + 1);
+    LAY(SAMSIM_A_M, k) = LAY(SAMSIM_A_M, k + 1);
+  }
+  const double mN = thN * rho_l;
+  LAY(SAMSIM_A_M, N) = mN;
+  LAY(SAMSIM_A_H_ABS, N) = mN * g.T_bottom * c_l;
+  LAY(SAMSIM_A_S_ABS, N) = mN * g.S_bu_bottom;
+}
+
+// layer_dynamics, mo_layer_dynamics.f90:64-175: exactly one branch per call, in priority order
+__device__ void layer_dynamics(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, Na = c.Na, N_top = g.n_top, bf = g.bottom_flag;
+  const double thick_0 = g.thick_0;
+  const int km1 = (Na - 1 > 1) ? Na - 1 : 1;
+  const double phi_Na = LAY(SAMSIM_A_PHI, Na), phi_km1 = LAY(SAMSIM_A_PHI, km1);
+  const double phi_Nm1 = LAY(SAMSIM_A_PHI, N - 1), phi_N = LAY(SAMSIM_A_PHI, N);
+  const double th_mid = LAY(SAMSIM_A_THICK, N_top + 1), th1 = LAY(SAMSIM_A_THICK, 1);
+  if (phi_Nm1 <= psi_s_min / 2.0 && phi_Na < 0.00001 && Na == N && th_mid / thick_0 > 1.000001 && bf == 1) {
+    bottom_melt(c, x);
+  } else if (Na > 1 && Na < N && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && bf == 1) {
+    zero_layer(c, Na); c.Na = Na - 1;  // bottom_melt_simple, :573-591
+  } else if (Na > 1 && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && (th_mid / thick_0) < 1.01 && bf == 1) {
+    zero_layer(c, Na); c.Na = Na - 1;
+  } else if (phi_Na > psi_s_min && Na < N && bf == 1) {
+    // bottom_growth_simple, :537-560
+    const double mnew = thick_0 * rho_l;
+    c.Na = Na + 1;
+    LAY(SAMSIM_A_THICK, Na + 1) = thick_0;
+    LAY(SAMSIM_A_M, Na + 1) = mnew;
+    LAY(SAMSIM_A_H_ABS, Na + 1) = mnew * g.T_bottom * c_l;
+    LAY(SAMSIM_A_S_ABS, Na + 1) = mnew * g.S_bu_bottom;
+  } else if (phi_N > psi_s_min && bf == 1) {
+    bottom_growth(c, x);
+  } else if (th1 > 1.5 * thick_0) {
+    c.melt_out3 = c.melt_out3 - th1;
+    top_grow(c, x);
+    c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
+  } else if (th1 < 0.5 * thick_0) {
+    c.melt_out3 = c.melt_out3 - th1;
+    top_melt(c, x);
+    if (c.status) return;
+    c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
+  }
+}
+
+// ---------------------------------------------------------------- output snapshot, mo_grotz.f90:340-398
+__device__ void output_point(Col &c, const Ctx &x, long long col, double time) {
+  const samsim_config &g = x.p->cfg;
+  const DevParams *p = x.p;
+  if (c.Na > 1) c.freeboard = func_freeboard(c, x); else c.freeboard = 0.0;
+  if (g.grav_flag == 2) {
+    if (c.grav_drain == 0.0) c.grav_temp = 0.0; else c.grav_temp = c.grav_temp / c.grav_drain;
+    c.grav_salt = c.grav_salt / g.time_out;
+    c.grav_drain = c.grav_drain / g.time_out;
+  }
+  if (col >= p->out_col0 && col < p->out_col0 + p->out_ncols) {
+    const size_t oc = (size_t)(col - p->out_col0), on = (size_t)p->out_ncols;
+    for (int a = 0; a < SAMSIM_NARR; ++a)
+      if (a != SAMSIM_A_RAY)
+        for (int k = 1; k <= c.N; ++k) p->out_lay[((size_t)a * c.N + (k - 1)) * on + oc] = LAY(a, k);
+    double *o = p->out_scal + oc;
+#define OUT(idx, v) o[(size_t)(idx) * on] = (v)
+    OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
+    OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
+    OUT(SAMSIM_S_PSI_G_SNOW, c.psi_g_snow); OUT(SAMSIM_S_T_SNOW, c.T_snow); OUT(SAMSIM_S_PHI_S, c.phi_s);
+    OUT(SAMSIM_S_T_TOP, c.T_top); OUT(SAMSIM_S_MELT_THICK, c.melt_thick); OUT(SAMSIM_S_T2M, c.T2m);
+    OUT(SAMSIM_S_LIQUID_PRECIP, c.liquid_precip); OUT(SAMSIM_S_SOLID_PRECIP, c.solid_precip); OUT(SAMSIM_S_FL_Q_BOTTOM, c.fl_q_bottom);
+    OUT(SAMSIM_S_GRAV_DRAIN, c.grav_drain); OUT(SAMSIM_S_GRAV_SALT, c.grav_salt); OUT(SAMSIM_S_GRAV_TEMP, c.grav_temp);
+    OUT(SAMSIM_S_MELT_OUT1, c.melt_out1); OUT(SAMSIM_S_MELT_OUT2, c.melt_out2); OUT(SAMSIM_S_MELT_OUT3, c.melt_out3);
+    OUT(SAMSIM_S_MELT_ERR, c.melt_err); OUT(SAMSIM_S_FREEBOARD, c.freeboard); OUT(SAMSIM_S_T_FREEZE, c.T_freeze);
+    OUT(SAMSIM_S_ALBEDO, c.albedo); OUT(SAMSIM_S_FL_SW, c.fl_sw); OUT(SAMSIM_S_FL_LW, c.fl_lw);
+    OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
+    OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
+    OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
+    OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
+#undef OUT
+    p->out_n_active[oc] = c.Na;
+  }
+  c.grav_drain = 0.0; c.grav_salt = 0.0; c.grav_temp = 0.0;
+  c.melt_out1 = 0.0; c.melt_out2 = 0.0; c.melt_out3 = 0.0;
+  (void)time;
+}
+
+// ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
+__device__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step) {
+  const samsim_config &g = x.p->cfg;
+  const DevParams *p = x.p;
+  const int N = c.N;
+
+  if (out_step) {
+    vital_signs(c, x);  // mo_grotz.f90:192-223; only ever read by `output`
+    // `output` prints the Rayleigh numbers of the PREVIOUS step's fl_grav_drain; S1 below overwrites them
+    if (col >= p->out_col0 && col < p->out_col0 + p->out_ncols) {
+      const size_t oc = (size_t)(col - p->out_col0), on = (size_t)p->out_ncols;
+      for (int k = 1; k <= N; ++k) p->out_lay[((size_t)SAMSIM_A_RAY * N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
+    }
+  }
+
+  // forcing, mo_grotz.f90:229-241 (+ ensemble perturbation)
+  if (g.atmoflux_flag == 2) {
+    if (time == time_input(tc)) {
+      c.T2m = p->f_T2m[tc - 1];
+      c.liquid_precip = p->f_precip[tc - 1];
+    } else {
+      const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
+      c.T2m = (1.0 - temp) * p->f_T2m[tc - 2] + temp * p->f_T2m[tc - 1];
+      c.liquid_precip = (1.0 - temp) * p->f_precip[tc - 2] + temp * p->f_precip[tc - 1];
+    }
+    c.T2m = c.T2m + c.dT2m;
+    c.liquid_precip = c.liquid_precip * c.precip_scale;
+  }
+
+  snow_fall(c, x);                  // mo_grotz.f90:251-265
+  snow_block(c, x);                 // mo_grotz.f90:273-292
+  if (c.status) return;
+
+  sweep_thermo_expulsion(c, x);     // mo_grotz.f90:297-307 (+ Rayleigh numbers)
+  if (c.status) return;
+  sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
+
+  if (out_step) output_point(c, x, col, time);  // mo_grotz.f90:340-398
+
+  int Na = c.Na;
+  // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
+  {
+    const double psi_gN = LAY(SAMSIM_A_PSI_G, Na);
+    if (psi_gN > 0.0) {
+      const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
+      LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
+      LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
+      LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
+    }
+  }
+  // thin-snow coupling, mo_grotz.f90:418-420
+  if (c.m_snow > 0.0 && c.thick_snow < g.thick_min) {
+    snow_coupling(c, x);
+    if (c.status) return;
+  }
+  // flooding, mo_grotz.f90:428-445
+  if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
+    // without snow load the freeboard cannot be negative, and every later reader re-evaluates it
+    c.freeboard = func_freeboard(c, x);
+    if (c.freeboard < 0.0 && g.flood_flag == 2) {
+      flood(c, x);
+      if (g.grav_flag == 2) refresh_ray_top(c, x);
+    }
+  }
+  // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
+  if (g.turb_flag == 2) {
+    const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
+    double S_abs = LAY(SAMSIM_A_S_ABS, Na);
+    const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
+    S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+    LAY(SAMSIM_A_S_ABS, Na) = S_abs;
+  }
+
+  // testcase specifics, mo_grotz.f90:503-565
+  if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
+    for (int n = 1; n <= 20; ++n) {
+      if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+    }
+  } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
+    c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+  }
+
+  // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
+  const double beer0 = radiation_header(c, x, time, tc);
+  const bool do_grav = (g.grav_flag == 2 && Na > 1), do_beer = (g.boundflux_flag == 2);
+  c.frad = 0.0;
+  if (do_grav) {
+    sweep_grav_drain(c, x, do_beer, beer0);
+    if (c.status) return;
+  } else if (do_beer) {
+    sweep_beer(c, beer0);
+  }
+
+  // heat fluxes + second thermodynamic sweep, mo_grotz.f90:584-598
+  surface_flux(c, x);
+  sweep_heat_thermo(c, x);
+  if (c.status) return;
+
+  // snow thermodynamics again, mo_grotz.f90:603-625
+  const double melt_thick_snow_old = c.melt_thick_snow;
+  snow_block(c, x);
+  if (c.status) return;
+  c.melt_thick_snow = melt_thick_snow_old + c.melt_thick_snow;
+
+  // flushing preparations, mo_grotz.f90:632-664
+  bool fb_valid = false;
+  if (Na > 1 && g.flush_flag > 2 && g.boundflux_flag == 2) {
+    c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
+    c.melt_thick = 0.0;
+    c.freeboard = func_freeboard(c, x);
+    fb_valid = true;
+    if (c.freeboard > 0.0000000000001) {
+      const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
+      if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
+        double thick1 = LAY(SAMSIM_A_THICK, 1);
+        const double thick1_in = thick1;
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
+                       c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
+        if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
+          // sub_melt_snow, mo_functions.f90:443-474
+          double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1);
+          const double shift = 1.0 / dmax(c.psi_g_snow, 0.01) * c.melt_thick;
+          if (shift >= c.thick_snow) {
+            c.melt_thick = c.melt_thick - c.thick_snow * c.psi_g_snow;
+            H_abs = H_abs + c.H_abs_snow;
+            m = m + c.m_snow;
+            thick1 = thick1 + (1.0 - c.psi_g_snow) * c.thick_snow;
+            c.thick_snow = 0.0; c.m_snow = 0.0; c.H_abs_snow = 0.0;
+          } else {
+            H_abs = H_abs + shift / c.thick_snow * c.H_abs_snow;
+            c.H_abs_snow = c.H_abs_snow - shift / c.thick_snow * c.H_abs_snow;
+            m = m + shift / c.thick_snow * c.m_snow;
+            c.m_snow = c.m_snow - shift / c.thick_snow * c.m_snow;
+            thick1 = thick1 + shift - c.melt_thick;
+            c.thick_snow = c.thick_snow - shift;
+            c.melt_thick = 0.0;
+          }
+          LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+          LAY(SAMSIM_A_M, 1) = m;
+          fb_valid = false;
+        }
+        if (thick1 != thick1_in) { LAY(SAMSIM_A_THICK, 1) = thick1; fb_valid = false; }
+      }
+    }
+  }
+
+  // flushing, mo_grotz.f90:670-737
+  const bool flush_possible = (g.flush_flag == 5);
+  if (flush_possible && !fb_valid) c.freeboard = func_freeboard(c, x);
+  c.melt_out1 = c.melt_out1 + c.melt_thick;
+  c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
+  c.melt_thick = c.melt_thick + c.melt_thick_snow;
+  if (c.melt_thick_snow > 0.0) {
+    const double mts = c.melt_thick_snow;
+    double H1 = LAY(SAMSIM_A_H_ABS, 1), S1 = LAY(SAMSIM_A_S_ABS, 1), m1 = LAY(SAMSIM_A_M, 1);
+    H1 = H1 + mts * rho_l * c_l * c.T_snow;
+    S1 = S1 + mts * rho_l * S_br_clamped(x.salt, c.T_snow, c.S_abs_snow / c.m_snow);
+    m1 = m1 + mts * rho_l;
+    LAY(SAMSIM_A_H_ABS, 1) = H1; LAY(SAMSIM_A_S_ABS, 1) = S1; LAY(SAMSIM_A_M, 1) = m1;
+    LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + mts;
+    LAY(SAMSIM_A_S_BU, 1) = S1 / m1;
+  }
+  if (flush_possible && Na > 1 && c.freeboard > 0.001) {
+    if (c.melt_thick > 0.000000000001 && Na > 2 && c.freeboard > 0.0) {
+      if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation
+      flush3(c, x);
+      if (c.status) return;
+    }
+  }
+
+  // layer dynamics, mo_grotz.f90:755-795
+  if (Na > 1) {
+    const double th1 = LAY(SAMSIM_A_THICK, 1);
+    if (LAY(SAMSIM_A_PHI, Na) > psi_s_min || LAY(SAMSIM_A_PHI, Na - 1) <= psi_s_min / 2.0 || th1 / g.thick_0 > 1.5 ||
+        th1 / g.thick_0 < 0.5) {
+      layer_dynamics(c, x);
+      if (c.status) return;
+    }
+    Na = c.Na;
+    const int kn = (Na + 1 < N) ? Na + 1 : N;
+    if (Na < N && LAY(SAMSIM_A_THICK, kn) == 0.0) {  // scrub, :772-783
+      LAY(SAMSIM_A_T, Na + 1) = g.T_bottom;
+      LAY(SAMSIM_A_S_BU, Na + 1) = g.S_bu_bottom;
+      LAY(SAMSIM_A_PSI_L, Na + 1) = 1.0;
+      LAY(SAMSIM_A_PSI_S, Na + 1) = 0.0;
+    }
+  } else {
+    if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
+      layer_dynamics(c, x);
+      if (c.status) return;
+    }
+  }
+
+  // health check, mo_grotz.f90:808-819 (negative S_abs is clamped element-wise at the next sweep)
+  if (c.min_psi_s < 0.0) STOPC(1337, 0);
+  if (c.Na == 1) {
+    const double v = LAY(SAMSIM_A_S_ABS, 1);
+    if (v < 0.0) LAY(SAMSIM_A_S_ABS, 1) = 0.0;
+  }
+}
+
+#ifndef SAMSIM_WAVES
+#define SAMSIM_WAVES 1
+#endif
+__global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel(const DevParams *__restrict__ pp) {
+  const DevParams &p = *pp;
+  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= p.ncol) return;
+  Ctx x;
+  x.p = pp;
+  x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
+  if (p.cfg.salt_flag == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
+  else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
+
+  Col c;
+  c.lay = p.lay + col;
+  c.ncol = (size_t)p.ncol;
+  c.N = p.cfg.nlayer;
+  c.Na = p.n_active[col];
+  c.status = p.status[col];
+  c.err_layer = p.err_layer[col];
+  c.err_step = p.err_step[col];
+  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0;
+  const size_t nc = (size_t)p.ncol;
+  double *sc = p.scal + col;
+#define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
+  SLOAD(m_snow, SAMSIM_S_M_SNOW); SLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SLOAD(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
+  SLOAD(thick_snow, SAMSIM_S_THICK_SNOW); SLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SLOAD(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
+  SLOAD(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SLOAD(T_snow, SAMSIM_S_T_SNOW); SLOAD(phi_s, SAMSIM_S_PHI_S);
+  SLOAD(T_top, SAMSIM_S_T_TOP); SLOAD(melt_thick, SAMSIM_S_MELT_THICK); SLOAD(T2m, SAMSIM_S_T2M);
+  SLOAD(liquid_precip, SAMSIM_S_LIQUID_PRECIP); SLOAD(solid_precip, SAMSIM_S_SOLID_PRECIP); SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
+  SLOAD(grav_drain, SAMSIM_S_GRAV_DRAIN); SLOAD(grav_salt, SAMSIM_S_GRAV_SALT); SLOAD(grav_temp, SAMSIM_S_GRAV_TEMP);
+  SLOAD(melt_out1, SAMSIM_S_MELT_OUT1); SLOAD(melt_out2, SAMSIM_S_MELT_OUT2); SLOAD(melt_out3, SAMSIM_S_MELT_OUT3);
+  SLOAD(melt_err, SAMSIM_S_MELT_ERR); SLOAD(freeboard, SAMSIM_S_FREEBOARD); SLOAD(T_freeze, SAMSIM_S_T_FREEZE);
+  SLOAD(albedo, SAMSIM_S_ALBEDO); SLOAD(fl_sw, SAMSIM_S_FL_SW); SLOAD(fl_lw, SAMSIM_S_FL_LW);
+  SLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SLOAD(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
+  SLOAD(energy_stored, SAMSIM_S_ENERGY_STORED); SLOAD(freshwater, SAMSIM_S_FRESHWATER); SLOAD(total_resist, SAMSIM_S_TOTAL_RESIST);
+  SLOAD(thickness, SAMSIM_S_THICKNESS); SLOAD(bulk_salin, SAMSIM_S_BULK_SALIN);
+  SLOAD(dT2m, SAMSIM_S_DT2M); SLOAD(precip_scale, SAMSIM_S_PRECIP_SCALE);
+#undef SLOAD
+
+  // uniform clock (mo_data: time, i, n_time_out, time_counter) evolves identically in every lane
+  double time = p.time0;
+  long long step = p.step0;
+  int n_time_out = p.n_time_out0, tc = p.time_counter0;
+  long long work = 0;
+  for (long long s = 0; s < p.nsteps; ++s) {
+    if (p.cfg.atmoflux_flag == 2) {
+      if (time > time_input(tc)) tc = tc + 1;
+      if (tc > p.flen) tc = p.flen;
+    }
+    const bool out_step = (n_time_out == p.cfg.i_time_out) || (step + 1 == 1);
+    if (!c.status) {
+      c.step = step;
+      work += c.Na;
+      column_step(c, x, col, time, tc, out_step);
+    }
+    if (out_step) n_time_out = 0; else n_time_out = n_time_out + 1;
+    time = time + p.cfg.dt;
+    step = step + 1;
+  }
+
+  p.n_active[col] = c.Na;
+  p.status[col] = c.status;
+  p.err_layer[col] = c.err_layer;
+  p.err_step[col] = c.err_step;
+  p.work[col] += work;
+#define SSTORE(field, idx) sc[(size_t)(idx) * nc] = c.field
+  SSTORE(m_snow, SAMSIM_S_M_SNOW); SSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SSTORE(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
+  SSTORE(thick_snow, SAMSIM_S_THICK_SNOW); SSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SSTORE(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
+  SSTORE(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SSTORE(T_snow, SAMSIM_S_T_SNOW); SSTORE(phi_s, SAMSIM_S_PHI_S);
+  SSTORE(T_top, SAMSIM_S_T_TOP); SSTORE(melt_thick, SAMSIM_S_MELT_THICK); SSTORE(T2m, SAMSIM_S_T2M);
+  SSTORE(liquid_precip, SAMSIM_S_LIQUID_PRECIP); SSTORE(solid_precip, SAMSIM_S_SOLID_PRECIP); SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
+  SSTORE(grav_drain, SAMSIM_S_GRAV_DRAIN); SSTORE(grav_salt, SAMSIM_S_GRAV_SALT); SSTORE(grav_temp, SAMSIM_S_GRAV_TEMP);
+  SSTORE(melt_out1, SAMSIM_S_MELT_OUT1); SSTORE(melt_out2, SAMSIM_S_MELT_OUT2); SSTORE(melt_out3, SAMSIM_S_MELT_OUT3);
+  SSTORE(melt_err, SAMSIM_S_MELT_ERR); SSTORE(freeboard, SAMSIM_S_FREEBOARD); SSTORE(T_freeze, SAMSIM_S_T_FREEZE);
+  SSTORE(albedo, SAMSIM_S_ALBEDO); SSTORE(fl_sw, SAMSIM_S_FL_SW); SSTORE(fl_lw, SAMSIM_S_FL_LW);
+  SSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SSTORE(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
+  SSTORE(energy_stored, SAMSIM_S_ENERGY_STORED); SSTORE(freshwater, SAMSIM_S_FRESHWATER); SSTORE(total_resist, SAMSIM_S_TOTAL_RESIST);
+  SSTORE(thickness, SAMSIM_S_THICKNESS); SSTORE(bulk_salin, SAMSIM_S_BULK_SALIN);
+#undef SSTORE
+}
+
+}  // namespace
+
+// d_params: device copy of the parameter block; ncol: number of columns it describes
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, long long ncol, hipStream_t stream) {
+  const int block = SAMSIM_BLOCK;
+  const long long grid = (ncol + block - 1) / block;
+  hipLaunchKernelGGL(samsim_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params);
+  return hipGetLastError();
+}

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/ (run in the BUILD container only; needs /root/reference and the
+flang-built reference under oracle/_ref, see oracle/build_ref.sh).
+
+Fixtures are DATA only -- inputs and expected outputs:
+  tc1_reference_dat.npz     the reference's own committed known answers
+                            reference_output/Reference_testcase1_with_Version_2/dat_*.dat (3 decimals, 72 rows)
+  sheba_forcing.npz         the four 3-hourly ERA-interim SHEBA tables the reference reads (first 13148 values,
+                            mo_grotz.f90:132; root-level *.txt.input == input/ERA-interim/sheba-p2)
+  tc1_ref_fullprec.npz      float64 dumps of the unmodified reference physics (oracle/_ref/samsim_ref_dump 1),
+                            all 72 output points
+  tc4_ref_fullprec.npz      same for testcase 4 (SHEBA): per-layer state at selected output days, every scalar at
+                            every output day of the first 500 days, and melt-season teacher-forcing pairs
+  tc1_spunup_state.npz /    step-boundary checkpoints (all SoA arrays + clock) produced with the CPU oracle, used as
+  tc4_spunup_state.npz      start states for parity tests and bench.py
+  func_golden.npz           function-level vectors from the reference modules (oracle/ref_hook/func_harness.f90)
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from samsim_amd import testcases as tcs  # noqa: E402
+from samsim_amd.capi import ARRAYS, SCALARS  # noqa: E402
+from tests.oracle_lib import oracle_solver  # noqa: E402
+from tests.refdump import read_dump, REF_SCALARS  # noqa: E402
+
+REF = "/root/reference"
+RUN = os.path.join(ROOT, "oracle", "_ref", "run")
+OUT = os.path.dirname(os.path.abspath(__file__))
+LAYER_KEYS = ["H_abs", "S_abs", "m", "thick", "T", "phi", "psi_s", "psi_l", "psi_g", "S_bu", "S_br", "ray", "perm",
+              "flush_v", "flush_h"]
+
+
+def run_ref(testcase, dump, env=None):
+    e = dict(os.environ, SAMSIM_REF_DUMP=dump, **(env or {}))
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "samsim_ref_dump"), str(testcase)], cwd=RUN, env=e,
+                          stdout=subprocess.DEVNULL)
+    return read_dump(os.path.join(RUN, dump))
+
+
+def pack(recs, with_layers=True):
+    d = dict(step=np.array([r["step"] for r in recs]), N_active=np.array([r["N_active"] for r in recs]),
+             time_counter=np.array([r["time_counter"] for r in recs]))
+    for i, n in enumerate(REF_SCALARS):
+        d["s_" + n] = np.array([r["scal"][n] for r in recs])
+    if with_layers:
+        for n in LAYER_KEYS:
+            d["a_" + n] = np.stack([r["arr"][n] for r in recs])
+    return d
+
+
+def reference_dat():
+    d = {}
+    base = os.path.join(REF, "reference_output", "Reference_testcase1_with_Version_2")
+    for n in ["T", "S_bu", "psi_s", "psi_l", "psi_g", "thick", "ray", "freeboard", "vital_signs", "grav_drain", "snow"]:
+        d[n] = np.loadtxt(os.path.join(base, f"dat_{n}.dat"))
+    with open(os.path.join(base, "dat_settings.dat")) as f:
+        d["settings_text"] = np.array(f.read())
+    np.savez_compressed(os.path.join(OUT, "tc1_reference_dat.npz"), **d)
+
+
+def forcing():
+    sw, lw, t2m, pr = tcs.read_forcing(REF)
+    np.savez_compressed(os.path.join(OUT, "sheba_forcing.npz"), fl_sw=sw, fl_lw=lw, T2m=t2m, precip=pr)
+
+
+def save_state(path, solver, cfg):
+    st = solver.get_state()
+    clk = solver.get_clock()
+    np.savez_compressed(path, lay=st.lay, scal=st.scal, n_active=st.n_active, time=clk.time, step=clk.step,
+                        n_time_out=clk.n_time_out, time_counter=clk.time_counter, n_outputs=clk.n_outputs,
+                        arrays=np.array(ARRAYS), scalars=np.array(SCALARS))
+
+
+def func_golden():
+    """function-level vectors: run oracle/_ref/samsim_ref_func, repack its blocks by tag"""
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "samsim_ref_func")], cwd=RUN)
+    raw = np.fromfile(os.path.join(RUN, "func_golden.bin"), dtype=np.uint8)
+    pos, d = 0, {}
+    names = {1: "getT_salt1", 2: "getT_salt2", 3: "liquidus_salt1", 4: "liquidus_salt2", 5: "density_ksnow",
+             6: "albedo", 7: "expulsion", 8: "freeboard"}
+    while pos < len(raw):
+        tag, ncols, nrows, _ = (int(v) for v in raw[pos:pos + 16].view(np.int32))
+        pos += 16
+        d[names[tag]] = raw[pos:pos + 8 * ncols * nrows].view(np.float64).reshape(nrows, ncols).copy()
+        pos += 8 * ncols * nrows
+    np.savez_compressed(os.path.join(OUT, "func_golden.npz"), **d)
+
+
+def main():
+    reference_dat()
+    forcing()
+    func_golden()
+    # --- testcase 1, all output points at full precision (bgc off: T/phi/S unaffected)
+    recs = run_ref(1, "tc1_dump.bin", {"SAMSIM_REF_BGC": "0"})
+    np.savez_compressed(os.path.join(OUT, "tc1_ref_fullprec.npz"), **pack(recs))
+    # --- testcase 4 / SHEBA full run (about 12 minutes)
+    full = os.path.join(RUN, "tc4_full.bin")
+    recs = read_dump(full) if os.path.exists(full) else run_ref(4, "tc4_full.bin")
+    days_layers = [1, 2, 3, 5, 10, 20, 40, 60, 66, 67, 68, 80, 100, 150, 200, 250, 300, 330, 340, 345, 346, 347, 348,
+                   349, 350, 360, 400, 450, 500, 600, 700, 800, 1000, 1200, 1400, 1600, len(recs)]
+    sel = [recs[d - 1] for d in days_layers if d - 1 < len(recs)]
+    d = pack(sel)
+    d["day_index"] = np.array([x for x in days_layers if x - 1 < len(recs)])
+    allsc = pack(recs, with_layers=False)
+    for k, v in allsc.items():
+        d["all_" + k] = v
+    # teacher-forcing pairs in the melt season: full mid-step state at output day D and at D+1
+    pairs = [347, 355, 365, 700, 720, 1060]
+    tf = pack([recs[i - 1] for p in pairs for i in (p, p + 1)])
+    for k, v in tf.items():
+        d["tf_" + k] = v
+    d["tf_days"] = np.array(pairs)
+    np.savez_compressed(os.path.join(OUT, "tc4_ref_fullprec.npz"), **d)
+
+    # --- spun-up step-boundary checkpoints from the oracle
+    cfg, st = tcs.testcase1(1)
+    o = oracle_solver(cfg, 1)
+    o.set_state(st)
+    o.set_clock()
+    o.step(200000)
+    save_state(os.path.join(OUT, "tc1_spunup_state.npz"), o, cfg)
+    f = tcs.read_forcing(REF)
+    for day, name in [(200, "tc4_spunup_state.npz"), (340, "tc4_melt_state.npz")]:
+        cfg, st = tcs.testcase4(1)
+        o = oracle_solver(cfg, 1)
+        o.set_forcing(*f)
+        o.set_state(st)
+        o.set_clock()
+        o.step(8640 * day)
+        save_state(os.path.join(OUT, name), o, cfg)
+
+
+if __name__ == "__main__":
+    main()

@@ -39,5 +39,29 @@ def load_oracle() -> C.CDLL:
     return _lib
 
 
-def oracle_solver(cfg, ncol) -> Solver:
-    return Solver(load_oracle(), "oracle_", cfg, ncol)
+class OracleSolver(Solver):
+    """the CPU oracle behind the same Python face as the HIP solver (oracle_* mirrors samsim_*, oracle/samsim_oracle.h)"""
+
+    def _create(self, device):
+        f = self._f("create")
+        f.argtypes, f.restype = [C.POINTER(type(self.cfg)), C.c_int64, C.POINTER(C.c_void_p)], C.c_int
+        return f(C.byref(self.cfg), C.c_int64(self.ncol), C.byref(self._h))
+
+    def _bind_extra(self):
+        f = self._f("step_part_b")
+        f.argtypes, f.restype = [C.c_void_p], C.c_int
+        f = self._f("set_threads")
+        f.argtypes, f.restype = [C.c_void_p, C.c_int], None
+
+    def synchronize(self):
+        pass
+
+    def step_part_b(self):
+        self._chk(self._f("step_part_b")(self._h), "step_part_b")
+
+    def set_threads(self, n):
+        self._f("set_threads")(self._h, n)
+
+
+def oracle_solver(cfg, ncol) -> OracleSolver:
+    return OracleSolver(load_oracle(), "oracle_", cfg, ncol)

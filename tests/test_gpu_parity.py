@@ -1,0 +1,280 @@
+"""Parity tests proper: the HIP path (through the C-ABI of include/samsim.h) against the CPU oracle on the same
+seeded inputs, against committed golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Bar (BASELINE.json north_star): per-layer T / phi / S within 1e-6 relative; integers (N_active, STOP
+codes, step indices) exact."""
+import os
+
+import numpy as np
+import pytest
+
+import samsim_amd
+from samsim_amd import testcases as tcs
+from samsim_amd.capi import SCALARS
+from tests.helpers import RTOL, assert_state_close, golden, load_checkpoint, rel_err, sheba_forcing
+from tests.oracle_lib import oracle_solver
+
+pytestmark = pytest.mark.gpu
+
+NTHREADS = min(16, len(os.sched_getaffinity(0)))
+
+
+def pair(cfg, ncol, st, clock=None, forcing=None, perturb=True, col0=0):
+    """a HIP solver and an oracle solver with identical inputs"""
+    g = samsim_amd.hip_solver(cfg, ncol)
+    o = oracle_solver(cfg, ncol)
+    o.set_threads(NTHREADS)
+    for s in (g, o):
+        if forcing is not None:
+            dT, ps = tcs.ensemble_perturbation(ncol, col0) if perturb else (None, None)
+            s.set_forcing(*forcing, dT, ps)
+        s.set_state(st)
+        s.set_clock(**(clock or {}))
+    return g, o
+
+
+def check(g, o, what, rtol=RTOL):
+    sg, so = g.get_state(), o.get_state()
+    stg, sto = g.get_status()[0], o.get_status()[0]
+    assert np.array_equal(stg, sto), f"{what}: STOP codes differ {np.unique(stg)} vs {np.unique(sto)}"
+    assert_state_close(sg, so, rtol, what=what)
+    return sg, so
+
+
+def test_tc1_from_open_water_identical_columns():
+    """cfg2 in small: testcase-1 forcing replicated to identical columns; every column must stay bitwise equal to
+    column 0 and column 0 must follow the oracle (freezing from a single water layer, first regrids)"""
+    ncol = 192
+    cfg, st = tcs.testcase1(ncol)
+    g, o = pair(cfg, ncol, st)
+    done = 0
+    for upto in (1, 2, 50, 3601, 3602, 20000):
+        g.step(upto - done)
+        o.step(upto - done)
+        done = upto
+        sg, so = check(g, o, f"tc1 step {upto}")
+        assert (sg.lay == sg.lay[:, :, :1]).all() and (sg.scal == sg.scal[:, :1]).all(), "identical columns diverged"
+    assert int(sg.n_active[0]) > 5
+    assert g.get_clock().time == o.get_clock().time == 20000.0
+
+
+def test_tc1_output_snapshots_match_golden_and_oracle():
+    """the `output` snapshot (mo_output.f90:129-144) at the first output points: vs oracle and vs the flang reference dump"""
+    cfg, st = tcs.testcase1(4)
+    g, o = pair(cfg, 4, st)
+    g.set_output_window(0, 4)
+    o.set_output_window(0, 4)
+    ref = golden("tc1_ref_fullprec.npz")
+    for i in range(4):
+        assert g.steps_to_output() == o.steps_to_output()
+        og, oo = g.run_to_output(), o.run_to_output()
+        assert og.step == oo.step == ref["step"][i]
+        assert np.array_equal(og.n_active, oo.n_active) and og.n_active[0] == ref["N_active"][i]
+        na = int(oo.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "psi_g", "S_bu", "thick", "ray", "H_abs", "S_abs", "m"]:
+            k = na - 1 if n == "ray" else na
+            assert rel_err(og.arr(n)[:k], oo.arr(n)[:k]) <= RTOL, f"output {i}: {n} vs oracle"
+            assert rel_err(og.arr(n)[:k, 0], ref["a_" + n][i, :k]) <= RTOL, f"output {i}: {n} vs reference dump"
+        for n in ["freeboard", "energy_stored", "freshwater", "total_resist", "thickness", "bulk_salin", "grav_drain",
+                  "grav_salt", "grav_temp", "T_top"]:
+            assert rel_err(og.sc(n), oo.sc(n)) <= RTOL, f"output {i}: scalar {n}"
+            assert rel_err(og.sc(n)[0], ref["s_" + n][i]) <= RTOL, f"output {i}: scalar {n} vs reference dump"
+
+
+def test_tc1_spun_up_state():
+    """75 active layers, gravity drainage active in most layers"""
+    st1, clock = load_checkpoint("tc1_spunup_state.npz")
+    cfg, _ = tcs.testcase1(1)
+    ncol = 64
+    g, o = pair(cfg, ncol, st1.replicate(ncol), clock)
+    g.step(5000)
+    o.step(5000)
+    sg, so = check(g, o, "tc1 spun-up +5000")
+    assert int(so.n_active[0]) >= 60
+    assert rel_err(sg.arr("ray")[:60], so.arr("ray")[:60]) <= RTOL
+
+
+def test_sheba_from_open_water_perturbed_ensemble():
+    """cfg3 in small: SHEBA forcing, perturbed T2m / precipitation per column, first three days (open water, rain and
+    snow into water, first ice layers, surface energy balance)"""
+    ncol = 64
+    cfg, st = tcs.testcase4(ncol)
+    g, o = pair(cfg, ncol, st, forcing=sheba_forcing())
+    for upto, n in ((1, 1), (8642, 8641), (26000, 17358)):
+        g.step(n)
+        o.step(n)
+        sg, so = check(g, o, f"sheba step {upto}")
+    assert len(np.unique(sg.arr("H_abs")[0])) > ncol // 2, "perturbation did not spread the ensemble"
+
+
+def test_sheba_spun_up_winter():
+    """day 200: full-depth ice (N_active = Nlayer region, elastic middle layers), snow cover, bottom growth"""
+    st1, clock = load_checkpoint("tc4_spunup_state.npz")
+    cfg, _ = tcs.testcase4(1)
+    ncol = 64
+    g, o = pair(cfg, ncol, st1.replicate(ncol), clock, forcing=sheba_forcing())
+    g.step(4000)
+    o.step(4000)
+    sg, so = check(g, o, "sheba day 200 +4000")
+    assert so.sc("thick_snow").min() > 0.0
+
+
+def test_sheba_melt_season_one_day():
+    """day 340 (melt onset): flushing (flush3), snow melt water, melt ponds, flooding checks, top melt regrids;
+    one full output interval so that the snapshot path is covered too"""
+    st1, clock = load_checkpoint("tc4_melt_state.npz")
+    cfg, _ = tcs.testcase4(1)
+    ncol = 48
+    g, o = pair(cfg, ncol, st1.replicate(ncol), clock, forcing=sheba_forcing())
+    g.set_output_window(0, ncol)
+    o.set_output_window(0, ncol)
+    n = g.steps_to_output()
+    assert n == o.steps_to_output()
+    og, oo = g.run_to_output(), o.run_to_output()
+    assert og.step == oo.step
+    for name in ["T", "psi_s", "psi_l", "S_bu", "thick", "perm", "flush_v", "flush_h"]:
+        assert rel_err(og.arr(name), oo.arr(name), 1e-7 if name != "perm" else 1e-30) <= 1e-5, name
+    for name in ["freeboard", "thick_snow", "T_snow", "thickness", "bulk_salin", "melt_out1", "melt_out2"]:
+        assert rel_err(og.sc(name), oo.sc(name), 1e-7) <= 1e-5, name
+    check(g, o, "sheba melt season", rtol=1e-5)
+    g.step(3000)
+    o.step(3000)
+    check(g, o, "sheba melt season +3000", rtol=1e-5)
+
+
+def test_launch_granularity_does_not_change_results():
+    """1000 steps in one launch == 10 launches of 100 == 1000 launches of 1 (bitwise): the uniform clock carried by the
+    host and the state carried in HBM are the whole state"""
+    st1, clock = load_checkpoint("tc4_spunup_state.npz")
+    cfg, _ = tcs.testcase4(1)
+    ncol = 128
+    res = []
+    for chunk in (1000, 100, 7):
+        g = samsim_amd.hip_solver(cfg, ncol)
+        dT, ps = tcs.ensemble_perturbation(ncol)
+        g.set_forcing(*sheba_forcing(), dT, ps)
+        g.set_state(st1.replicate(ncol))
+        g.set_clock(**clock)
+        done = 0
+        while done < 1000:
+            n = min(chunk, 1000 - done)
+            g.step(n)
+            done += n
+        res.append((g.get_state(), g.get_clock()))
+        g.close()
+    for st, clk in res[1:]:
+        assert np.array_equal(st.lay, res[0][0].lay) and np.array_equal(st.scal, res[0][0].scal)
+        assert np.array_equal(st.n_active, res[0][0].n_active)
+        assert (clk.time, clk.step, clk.n_time_out, clk.time_counter) == (
+            res[0][1].time, res[0][1].step, res[0][1].n_time_out, res[0][1].time_counter)
+
+
+def test_state_roundtrip_and_column_windows():
+    cfg, st = tcs.testcase4(10)
+    rng = np.random.default_rng(7)
+    st.lay[:] = rng.random(st.lay.shape)
+    st.scal[:] = rng.random(st.scal.shape)
+    st.n_active[:] = rng.integers(1, cfg.nlayer + 1, size=10)
+    g = samsim_amd.hip_solver(cfg, 10)
+    g.set_state(st)
+    back = g.get_state()
+    assert np.array_equal(back.lay, st.lay) and np.array_equal(back.scal, st.scal) and np.array_equal(back.n_active, st.n_active)
+    w = st.window(3, 4)
+    w.lay[:] = -1.0
+    g.set_state(w, col0=3)
+    back = g.get_state()
+    assert (back.lay[:, :, 3:7] == -1.0).all() and np.array_equal(back.lay[:, :, :3], st.lay[:, :, :3])
+    part = g.get_state(col0=6, ncols=3)
+    assert np.array_equal(part.lay, back.lay[:, :, 6:9])
+    with pytest.raises(samsim_amd.SamsimError):
+        g.set_state(st, col0=5)  # does not fit
+
+
+def test_failed_columns_are_frozen_and_reported():
+    """the reference aborts the whole program with STOP n; here the column records n and freezes while its
+    neighbours keep running.  Codes, first failing step and healthy columns must match the oracle."""
+    st1, clock = load_checkpoint("tc1_spunup_state.npz")
+    cfg, _ = tcs.testcase1(1)
+    ncol = 8
+    st = st1.replicate(ncol)
+    st.arr("S_abs")[3, 2] = -5.0e3      # strongly negative salt -> gravity-drainage / health-check STOP
+    st.arr("H_abs")[0, 5] = -1.0e15     # absurd enthalpy -> getT cannot converge (STOP 99)
+    st.arr("m")[10, 6] = -st.arr("m")[10, 6]  # negative mass -> negative solid fraction (STOP 1337)
+    g, o = pair(cfg, ncol, st, clock)
+    g.step(300)
+    o.step(300)
+    (sg, stepg, layg), (so, stepo, layo) = g.get_status(), o.get_status()
+    assert np.array_equal(sg, so), (sg, so)
+    assert np.array_equal(stepg, stepo), (stepg, stepo)
+    assert set(np.nonzero(so)[0]) >= {5}, so
+    healthy = np.nonzero(so == 0)[0]
+    assert len(healthy) >= 5
+    a, b = g.get_state(), o.get_state()
+    for n in ["H_abs", "S_abs", "T"]:
+        assert rel_err(a.arr(n)[:, healthy], b.arr(n)[:, healthy]) <= RTOL
+
+
+def test_unsupported_flags_are_rejected():
+    cfg, _ = tcs.testcase1(1)
+    cfg.boundflux_flag = 3
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        samsim_amd.hip_solver(cfg, 4)
+    assert e.value.code == -2
+    cfg, _ = tcs.testcase1(1)
+    cfg.struct_size = 8
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        samsim_amd.hip_solver(cfg, 4)
+    assert e.value.code == -6
+
+
+def test_full_size_cfg2_replicas_stay_identical():
+    """BASELINE cfg2 size: 65 536 identical testcase-1 columns.  Property: every column equals column 0 bitwise after
+    2 000 steps (no cross-column interference at full occupancy), and column 0 equals the oracle."""
+    st1, clock = load_checkpoint("tc1_spunup_state.npz")
+    cfg, _ = tcs.testcase1(1)
+    ncol = 65536
+    g = samsim_amd.hip_solver(cfg, ncol)
+    rep = st1.replicate(8192)
+    for c0 in range(0, ncol, 8192):
+        g.set_state(rep, c0)
+    g.set_clock(**clock)
+    g.step(2000)
+    sg = g.get_state()
+    assert not g.get_status()[0].any()
+    assert (sg.lay == sg.lay[:, :, :1]).all() and (sg.n_active == sg.n_active[0]).all()
+    o = oracle_solver(cfg, 1)
+    o.set_state(st1)
+    o.set_clock(**clock)
+    o.step(2000)
+    assert_state_close(sg.window(0, 1), o.get_state(), what="cfg2 column 0")
+    cells, colsteps = g.get_work()
+    assert colsteps == (clock["step"] + 2000) * ncol and cells == 2000 * int(sg.n_active[0]) * ncol
+
+
+def test_full_size_cfg3_million_columns_properties():
+    """BASELINE cfg3 size: 1 048 576 SHEBA columns.  The perturbation is made periodic with period 4096, so column c and
+    c + 4096 must agree bitwise wherever they run on the chip; column 0..63 are checked against the oracle; no column may
+    trip the per-step energy-conservation assert (mo_heat_fluxes.f90:265-310, STOP 431) or any other STOP."""
+    st1, clock = load_checkpoint("tc4_spunup_state.npz")
+    cfg, _ = tcs.testcase4(1)
+    ncol, period, nsteps = 1 << 20, 4096, 300
+    dT, ps = tcs.ensemble_perturbation(period)
+    dT, ps = np.tile(dT, ncol // period), np.tile(ps, ncol // period)
+    g = samsim_amd.hip_solver(cfg, ncol)
+    g.set_forcing(*sheba_forcing(), dT, ps)
+    rep = st1.replicate(16384)
+    for c0 in range(0, ncol, 16384):
+        g.set_state(rep, c0)
+    g.set_clock(**clock)
+    g.step(nsteps)
+    assert not g.get_status()[0].any()
+    first = g.get_state(0, period, narr=4)
+    for c0 in (period, 37 * period, ncol - period):
+        other = g.get_state(c0, period, narr=4)
+        assert np.array_equal(other.lay, first.lay) and np.array_equal(other.n_active, first.n_active)
+    o = oracle_solver(cfg, 64)
+    o.set_threads(NTHREADS)
+    o.set_forcing(*sheba_forcing(), dT[:64], ps[:64])
+    o.set_state(st1.replicate(64))
+    o.set_clock(**clock)
+    o.step(nsteps)
+    assert_state_close(g.get_state(0, 64), o.get_state(), what="cfg3 columns 0..63")

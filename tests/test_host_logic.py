@@ -1,0 +1,54 @@
+"""Host-side mirror of mo_init (samsim_amd/testcases.py) and ensemble helpers; CPU only."""
+import re
+
+import numpy as np
+
+from samsim_amd import testcases as tcs
+from samsim_amd.capi import State, NARR, NSCAL
+from tests.helpers import golden
+
+
+def test_testcase1_settings_match_reference_dat_settings():
+    """dat_settings.dat of Reference_testcase1_with_Version_2 (the reference's echo of init, mo_output.f90:41-106)"""
+    text = str(golden("tc1_reference_dat.npz")["settings_text"])
+    kv = dict(re.findall(r"^(\w+)\s*=?\s+(-?[\d.]+)\s*$", text, flags=re.M))
+    cfg, st = tcs.testcase1(1)
+    assert float(kv["dt"]) == cfg.dt and float(kv["thick_0"]) == cfg.thick_0
+    assert float(kv["time_out"]) == cfg.time_out and float(kv["time_total"]) == cfg.time_total
+    assert float(kv["T_bottom"]) == cfg.T_bottom and float(kv["S_bu_bottom"]) == cfg.S_bu_bottom
+    assert int(kv["N_top"]) == cfg.n_top and int(kv["N_middle"]) == cfg.n_middle and int(kv["N_bottom"]) == cfg.n_bottom
+    assert int(kv["Nlayer"]) == cfg.nlayer
+    for flag in ["boundflux_flag", "atmoflux_flag", "albedo_flag", "grav_flag", "flush_flag", "flood_flag",
+                 "grav_heat_flag", "flush_heat_flag", "harmonic_flag", "prescribe_flag", "salt_flag", "turb_flag",
+                 "bottom_flag", "tank_flag"]:
+        assert int(kv[flag]) == getattr(cfg, flag), flag
+    assert cfg.precip_flag == 0 and re.search(r"^precip_flag\s*$", text, flags=re.M)  # I9.0 prints a zero as blanks
+    assert cfg.i_time_out == 3600 and tcs.i_time(cfg) == 259200 and cfg.thick_min == 0.001
+
+
+def test_testcase4_settings():
+    cfg, st = tcs.testcase4(3)
+    assert (cfg.nlayer, cfg.n_top, cfg.n_middle, cfg.n_bottom) == (100, 20, 60, 20)
+    assert (cfg.boundflux_flag, cfg.atmoflux_flag, cfg.precip_flag, cfg.flush_flag, cfg.flush_heat_flag) == (2, 2, 1, 5, 2)
+    assert cfg.i_time_out == 8640 and tcs.i_time(cfg) == 14191200
+    assert st.lay.shape == (NARR, 100, 3) and st.scal.shape == (NSCAL, 3)
+    assert (st.arr("thick")[0] == 0.01).all() and (st.arr("thick")[1:] == 0).all()
+    assert (st.arr("S_abs")[0] == 34.0 * (0.01 * 1028.0)).all() and (st.arr("H_abs") == 0).all()
+
+
+def test_ensemble_perturbation_is_counter_based():
+    dT, ps = tcs.ensemble_perturbation(1000)
+    assert dT[0] == 0.0 and ps[0] == 1.0
+    assert (np.abs(dT) <= 2.0).all() and (np.abs(ps - 1.0) <= 0.3).all()
+    assert np.std(dT) > 1.0 and np.std(ps) > 0.15
+    # a shard regenerates exactly its slice of the global sequence
+    dT2, ps2 = tcs.ensemble_perturbation(100, col0=500)
+    assert np.array_equal(dT2, dT[500:600]) and np.array_equal(ps2, ps[500:600])
+
+
+def test_state_replicate_and_window():
+    cfg, st = tcs.testcase1(1)
+    r = st.replicate(5)
+    assert r.lay.shape[2] == 5 and (r.lay == st.lay[:, :, :1]).all()
+    w = r.window(2, 2)
+    assert w.ncol == 2 and w.lay.flags.c_contiguous
