@@ -177,7 +177,10 @@ def test_state_roundtrip_and_column_windows():
     g = samsim_amd.hip_solver(cfg, 10)
     g.set_state(st)
     back = g.get_state()
-    assert np.array_equal(back.lay, st.lay) and np.array_equal(back.scal, st.scal) and np.array_equal(back.n_active, st.n_active)
+    nown = len(SCALARS) - 2  # the two perturbation slots are owned by set_forcing
+    assert np.array_equal(back.lay, st.lay) and np.array_equal(back.n_active, st.n_active)
+    assert np.array_equal(back.scal[:nown], st.scal[:nown])
+    assert (back.sc("dT2m") == 0.0).all() and (back.sc("precip_scale") == 1.0).all()
     w = st.window(3, 4)
     w.lay[:] = -1.0
     g.set_state(w, col0=3)
@@ -206,8 +209,8 @@ def test_failed_columns_are_frozen_and_reported():
     assert np.array_equal(sg, so), (sg, so)
     assert np.array_equal(stepg, stepo), (stepg, stepo)
     assert set(np.nonzero(so)[0]) >= {5}, so
-    healthy = np.nonzero(so == 0)[0]
-    assert len(healthy) >= 5
+    healthy = np.array([0, 1, 3, 4, 7])  # untouched columns next to the corrupted ones
+    assert not so[healthy].any()
     a, b = g.get_state(), o.get_state()
     for n in ["H_abs", "S_abs", "T"]:
         assert rel_err(a.arr(n)[:, healthy], b.arr(n)[:, healthy]) <= RTOL
