@@ -70,6 +70,8 @@ struct Col {
   double fl_Q1;      // fl_Q(1)
   double frad;       // fl_rad(N_active)
   double min_psi_s;  // MINVAL(psi_s(1:N_active)) of this step's Expulsion
+  double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
+  double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
 };
 
 #define LAY(a, k) c.lay[((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol]
@@ -417,7 +419,7 @@ __device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   double T_test = g.T_bottom;
   double minp = 1.0e300, stp = 0.0, st = 0.0;  // suffix min(perm), sum(thick/perm), sum(thick) over k..Na-1
   double S_br_bot = 0.0, bot = 0.0, botterm = 0.0, perm_bot = 0.0;
-  double min_psi_s = 1.0e300;
+  double min_psi_s = 1.0e300, buoy_s = 0.0;
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   for (int k = Na; k >= 1; --k) {
@@ -440,9 +442,10 @@ __device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     if (psi_l < 0.0) psi_l = 0.0;
     if (psi_g < 0.0) psi_g = 0.0;
     min_psi_s = dmin(min_psi_s, psi_s);
+    buoy_s += psi_s * thick;
+    // phi is not stored: the second sweep rewrites it before anything reads it.  S_bu is not stored either: the
+    // only reader before the refresh in P2 is mass_transfer's func_S_br(T, S_bu), which equals S_br bit for bit.
     LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_PHI, k) = phi;
-    LAY(SAMSIM_A_S_BU, k) = S_bu;
     LAY(SAMSIM_A_S_BR, k) = S_br;
     LAY(SAMSIM_A_PSI_S, k) = psi_s;
     LAY(SAMSIM_A_PSI_L, k) = psi_l;
@@ -475,6 +478,7 @@ __device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     }
   }
   c.min_psi_s = min_psi_s;
+  c.buoy_s = buoy_s;
   if (rc) STOPC(rc, rc_layer);
 }
 
@@ -483,43 +487,49 @@ __device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
 // (mo_mass.f90:53-96) with these fluxes (all <= 0: brine only moves down) needs the layer above only.  Then the
 // S_bu refresh of mo_grotz.f90:333-335.  mass_transfer is skipped on the first step (mo_grotz.f90:313).
 __device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
-  const Salt &s = x.salt;
   const int Na = c.Na;
   const bool transfer = (c.step + 1 != 1);
   double flm_k = 0.0;  // fl_m(k)
-  double T_up = 0.0, S_bu_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, snapshot S_bu, UPDATED S_abs
+  double buoy_g = 0.0;
+  double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
   for (int k = 1; k <= Na; ++k) {
     const double V_ex = LAY(D_V_EX, k);
     double m = LAY(SAMSIM_A_M, k);
     double flm_next;
+    double psi_g = LAY(SAMSIM_A_PSI_G, k);
     if (k == 1) {
       flm_next = -V_ex * rho_l;
+      if (psi_g > 0.0) buoy_g += psi_g * LAY(SAMSIM_A_THICK, k);
+    } else if (psi_g < (double)0.001f) {
+      flm_next = -V_ex * rho_l + flm_k;
+      if (psi_g > 0.0) buoy_g += psi_g * LAY(SAMSIM_A_THICK, k);
     } else {
-      double psi_g = LAY(SAMSIM_A_PSI_G, k);
-      if (psi_g < (double)0.001f) {
-        flm_next = -V_ex * rho_l + flm_k;
-      } else {
-        const double thick = LAY(SAMSIM_A_THICK, k);
-        flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
-        psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
-        LAY(SAMSIM_A_PSI_G, k) = psi_g;
-      }
+      const double thick = LAY(SAMSIM_A_THICK, k);
+      flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
+      psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
+      LAY(SAMSIM_A_PSI_G, k) = psi_g;
+      buoy_g += psi_g * thick;
     }
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
     double S_abs = LAY(SAMSIM_A_S_ABS, k);
-    const double T = LAY(SAMSIM_A_T, k), S_bu = LAY(SAMSIM_A_S_BU, k);
+    double T = 0.0, S_br = 0.0;
+    if (transfer && (flm_next < 0.0 || flm_k < 0.0)) {
+      T = LAY(SAMSIM_A_T, k);
+      S_br = LAY(SAMSIM_A_S_BR, k);  // == func_S_br(TT(k), SS_bu(k)) of mo_mass.f90:85
+    }
     if (transfer) {
-      double H_abs = LAY(SAMSIM_A_H_ABS, k);
+      double H_abs = 0.0;
       bool ch = false;
+      if (flm_next < 0.0 || flm_k < 0.0) H_abs = LAY(SAMSIM_A_H_ABS, k);
       if (flm_next < 0.0) {
         H_abs = H_abs + flm_next * T * c_l;
-        S_abs = S_abs + dmax(flm_next * S_br_clamped(s, T, S_bu), -S_abs);
+        S_abs = S_abs + dmax(flm_next * S_br, -S_abs);
         ch = true;
       }
       if (flm_k < 0.0) {
         H_abs = H_abs - flm_k * T_up * c_l;
-        S_abs = S_abs - dmax(flm_k * S_br_clamped(s, T_up, S_bu_up), -S_abs_up);
+        S_abs = S_abs - dmax(flm_k * S_br_up, -S_abs_up);
         ch = true;
       }
       if (ch) {
@@ -528,9 +538,10 @@ __device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
       }
     }
     LAY(SAMSIM_A_S_BU, k) = S_abs / m;
-    T_up = T; S_bu_up = S_bu; S_abs_up = S_abs;
+    T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_k = flm_next;
   }
+  c.buoy_g = buoy_g;
 }
 
 // ---------------------------------------------------------------- vital signs, mo_grotz.f90:192-223 (output only)
@@ -851,13 +862,14 @@ __device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
   int rc = 0, rc_layer = 0;
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l + LAY(SAMSIM_A_PSI_G, Na) * 0.0;
+  // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
+  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
   for (int k = Na; k >= 1; --k) {
     double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l + LAY(SAMSIM_A_PSI_G, k - 1) * 0.0;
+      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
       const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
@@ -1331,11 +1343,15 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   }
   // flooding, mo_grotz.f90:428-445
   if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
-    // without snow load the freeboard cannot be negative, and every later reader re-evaluates it
-    c.freeboard = func_freeboard(c, x);
-    if (c.freeboard < 0.0 && g.flood_flag == 2) {
-      flood(c, x);
-      if (g.grav_flag == 2) refresh_ray_top(c, x);
+    // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
+    // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
+    const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
+    if (c.m_snow > buoy) {
+      c.freeboard = (buoy - c.m_snow) / rho_l;
+      if (c.freeboard < 0.0 && g.flood_flag == 2) {
+        flood(c, x);
+        if (g.grav_flag == 2) refresh_ray_top(c, x);
+      }
     }
   }
   // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
@@ -1383,11 +1399,12 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   if (Na > 1 && g.flush_flag > 2 && g.boundflux_flag == 2) {
     c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
     c.melt_thick = 0.0;
-    c.freeboard = func_freeboard(c, x);
-    fb_valid = true;
-    if (c.freeboard > 0.0000000000001) {
-      const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
-      if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
+    const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
+    // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
+    if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
+      c.freeboard = func_freeboard(c, x);
+      fb_valid = true;
+      if (c.freeboard > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
         sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
@@ -1421,7 +1438,8 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   }
 
   // flushing, mo_grotz.f90:670-737
-  const bool flush_possible = (g.flush_flag == 5);
+  // freeboard (:670) is only read when flush3 can run (:715-716): flush_flag 5, N_active > 2 and melt water present
+  const bool flush_possible = (g.flush_flag == 5 && Na > 2 && c.melt_thick + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !fb_valid) c.freeboard = func_freeboard(c, x);
   c.melt_out1 = c.melt_out1 + c.melt_thick;
   c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
@@ -1436,9 +1454,9 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + mts;
     LAY(SAMSIM_A_S_BU, 1) = S1 / m1;
   }
-  if (flush_possible && Na > 1 && c.freeboard > 0.001) {
-    if (c.melt_thick > 0.000000000001 && Na > 2 && c.freeboard > 0.0) {
-      if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation
+  if (flush_possible && c.freeboard > 0.001) {
+    if (c.melt_thick > 0.000000000001) {
+      if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation (:717)
       flush3(c, x);
       if (c.status) return;
     }
