@@ -16,7 +16,7 @@
 
 #include "samsim_device.h"
 
-extern "C" hipError_t samsim_launch_step(const DevParams *d_params, long long ncol, hipStream_t stream);
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, hipStream_t stream);
 
 namespace {
 
@@ -45,6 +45,10 @@ struct samsim_handle {
   double *lay = nullptr, *scal = nullptr;
   int32_t *n_active = nullptr, *status = nullptr, *err_layer = nullptr;
   long long *err_step = nullptr, *work = nullptr;
+  double *spec = nullptr;      // hand-over block of the up sweep, [DEV_NSPEC][ncol]
+  int32_t *flags = nullptr;    // COLF_* per column
+  int buf = 0;                 // psi buffer that is current at the next step
+  int last_psi_buf = 0;        // psi buffer that was current during the last completed step
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
   int32_t flen = 0;
   double *out_lay = nullptr, *out_scal = nullptr;
@@ -138,6 +142,7 @@ int launch(samsim_handle *h, long long nsteps) {
   p.cfg = h->cfg;
   p.lay = h->lay; p.scal = h->scal; p.n_active = h->n_active; p.status = h->status; p.err_layer = h->err_layer;
   p.err_step = h->err_step; p.work = h->work;
+  p.spec = h->spec; p.flags = h->flags; p.buf0 = h->buf;
   p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
   p.ncol = h->ncol;
   p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
@@ -146,8 +151,10 @@ int launch(samsim_handle *h, long long nsteps) {
   p.out_col0 = h->out_col0; p.out_ncols = h->out_ncols;
   p.p17 = h->p17; p.p14 = h->p14; p.tf_c3 = h->tf_c3;
   HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(samsim_launch_step(&h->d_params[s], h->ncol, h->stream));
+  HIPCHK(samsim_launch_step(&h->d_params[s], &p, h->stream));
   HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
+  h->last_psi_buf = (int)((h->buf + nsteps - 1) & 1);
+  h->buf = (int)((h->buf + nsteps) & 1);
   advance_clock(h, nsteps);
   return SAMSIM_OK;
 }
@@ -206,6 +213,8 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   ok = ok && hip_ok(dalloc(&h->err_layer, nc), "hipMalloc err_layer");
   ok = ok && hip_ok(dalloc(&h->err_step, nc), "hipMalloc err_step");
   ok = ok && hip_ok(dalloc(&h->work, nc), "hipMalloc work");
+  ok = ok && hip_ok(dalloc(&h->spec, (size_t)DEV_NSPEC * nc), "hipMalloc spec");
+  ok = ok && hip_ok(dalloc(&h->flags, nc), "hipMalloc flags");
   ok = ok && hip_ok(dalloc(&h->d_params, (size_t)kRing), "hipMalloc params");
   ok = ok && hip_ok(hipHostMalloc((void **)&h->h_params, sizeof(DevParams) * kRing, hipHostMallocDefault), "hipHostMalloc params");
   for (int i = 0; ok && i < kRing; ++i) ok = hip_ok(hipEventCreateWithFlags(&h->slot_done[i], hipEventDisableTiming), "hipEventCreate");
@@ -218,13 +227,17 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
     ok = ok && hip_ok(hipMemsetAsync(h->err_layer, 0, sizeof(int32_t) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->err_step, 0, sizeof(long long) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->work, 0, sizeof(long long) * nc, h->stream), "memset");
+    ok = ok && hip_ok(hipMemsetAsync(h->spec, 0, sizeof(double) * DEV_NSPEC * nc, h->stream), "memset");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_T * N * nc, N * nc, cfg->T_bottom, h->stream), "fill T");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_S_BU * N * nc, N * nc, cfg->S_bu_bottom, h->stream), "fill S_bu");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_PSI_L * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
+    ok = ok && hip_ok(fill(h->lay + (size_t)D_PSI_L2 * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
     ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream), "fill precip_scale");
     if (ok) {
       hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->n_active, nc, 1);
-      ok = hip_ok(hipGetLastError(), "fill n_active");
+      hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->flags, nc,
+                         COLF_DIRTY | COLF_RESTART);
+      ok = hip_ok(hipGetLastError(), "fill n_active/flags");
     }
     ok = ok && hip_ok(hipStreamSynchronize(h->stream), "sync");
   }
@@ -241,6 +254,7 @@ void samsim_destroy(samsim_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
+  (void)hipFree(h->spec); (void)hipFree(h->flags);
   (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
   (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
   (void)hipFree(h->d_params);
@@ -302,6 +316,18 @@ int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0) 
                      hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->n_active + col0, s->n_active, w * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(h->status + col0, 0, w * sizeof(int32_t)));
+  if (s->narr == SAMSIM_NARR) {
+    // the volume fractions are double-buffered on the device (samsim_kernels.hip): fill the second buffer too
+    const int pub[3] = {SAMSIM_A_PSI_S, SAMSIM_A_PSI_L, SAMSIM_A_PSI_G}, alt[3] = {D_PSI_S2, D_PSI_L2, D_PSI_G2};
+    for (int i = 0; i < 3; ++i)
+      HIPCHK(hipMemcpy2D(h->lay + (size_t)alt[i] * N * nc + col0, nc * sizeof(double), s->lay + (size_t)pub[i] * N * w,
+                         w * sizeof(double), w * sizeof(double), N, hipMemcpyHostToDevice));
+  }
+  // the next step of these columns runs the full first sweep and treats RAY as the previous step's Rayleigh numbers
+  hipLaunchKernelGGL(fill_i32, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, h->stream, h->flags + col0, w,
+                     COLF_DIRTY | COLF_RESTART);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
   return SAMSIM_OK;
 }
 
@@ -314,6 +340,14 @@ int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy2D(s->lay, w * sizeof(double), h->lay + col0, nc * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
                      hipMemcpyDeviceToHost));
+  if (s->narr == SAMSIM_NARR && h->last_psi_buf == 1) {
+    // psi_s / psi_l / psi_g of the last completed step live in the second buffer (the first one already holds the
+    // fractions the up sweep prepared for the next step)
+    const int pub[3] = {SAMSIM_A_PSI_S, SAMSIM_A_PSI_L, SAMSIM_A_PSI_G}, alt[3] = {D_PSI_S2, D_PSI_L2, D_PSI_G2};
+    for (int i = 0; i < 3; ++i)
+      HIPCHK(hipMemcpy2D(s->lay + (size_t)pub[i] * N * w, w * sizeof(double), h->lay + (size_t)alt[i] * N * nc + col0,
+                         nc * sizeof(double), w * sizeof(double), N, hipMemcpyDeviceToHost));
+  }
   HIPCHK(hipMemcpy2D(s->scal, w * sizeof(double), h->scal + col0, nc * sizeof(double), w * sizeof(double), (size_t)SAMSIM_NSCAL,
                      hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(s->n_active, h->n_active + col0, w * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -14,9 +14,22 @@
 // device-internal layer arrays: the public ones (enum samsim_layer_array) followed by scratch
 enum dev_layer_array {
   D_V_EX = SAMSIM_NARR,   // expelled brine volume V_ex(k) (mo_thermo_functions.f90:157); reused as R(k) in flush3
-  D_FLM,                  // not stored by the fused passes; kept for debugging
+  D_PSI_S2, D_PSI_L2, D_PSI_G2,  // second buffer of the volume fractions: the up sweep of step n reads the fractions of
+                                 // step n for the conductive stencil while it writes those of step n+1 (see samsim_kernels.hip)
   DEV_NARR
 };
+
+// per-column values handed from the up sweep of step n to the top-layer prologue of step n+1: [DEV_NSPEC][ncol]
+enum dev_spec {
+  SP_MINP = 0, SP_STP, SP_ST,               // suffix min(perm), sum(thick/perm), sum(thick) over layers 2..N_active-1
+  SP_BOT, SP_BOTTERM, SP_PERM_BOT, SP_SBR_BOT,  // bottom-layer terms of the Rayleigh number
+  SP_BUOY_S, SP_MIN_PSI_S,                  // partial SUM(psi_s*thick), MIN(psi_s) over layers 2..N_active
+  DEV_NSPEC
+};
+
+// per-column flag bits
+#define COLF_DIRTY 1    // prognostic layers changed since the last up sweep: the next step runs the full S1 sweep
+#define COLF_RESTART 2  // first step after samsim_set_state: RAY holds the previous Rayleigh numbers
 
 struct DevParams {
   samsim_config cfg;
@@ -27,6 +40,9 @@ struct DevParams {
   int32_t *err_layer;
   long long *err_step;
   long long *work;
+  double *spec;         // [DEV_NSPEC][ncol]
+  int32_t *flags;       // [ncol] COLF_*
+  int32_t buf0;         // which psi buffer is current at the first step of this launch (0: SAMSIM_A_PSI_*, 1: D_PSI_*2)
   const double *f_sw, *f_lw, *f_T2m, *f_precip;
   int32_t flen;
   long long ncol;

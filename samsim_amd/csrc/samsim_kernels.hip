@@ -47,6 +47,14 @@ constexpr double emissivity_ice = 0.95, emissivity_snow = 1.00, penetr = 0.30, e
 constexpr double Turb_A = 0.1 * 0.05 * rho_l / 86400.0;
 constexpr double Turb_B = 0.05;
 
+// Functions off the common path (snow, flooding, flushing, regridding, output, the unfused sweeps) can be kept out of
+// line (tuning knob SAMSIM_OUTLINE_RARE, off: measured slower because the column struct then lives in scratch).
+#if defined(SAMSIM_OUTLINE_RARE) && SAMSIM_OUTLINE_RARE
+#define RARE __attribute__((noinline))
+#else
+#define RARE
+#endif
+
 struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
   double c2, c3, c4, d2, d3, d4;
 };
@@ -56,6 +64,10 @@ struct Col {
   size_t ncol;
   int N;
   int Na;       // N_active
+  int ps, pl, pg;     // array ids of the CURRENT psi_s / psi_l / psi_g buffers (this step's Expulsion)
+  int nps, npl, npg;  // array ids of the buffers the up sweep fills for the next step
+  int flags;          // COLF_*
+  double *spec;       // [DEV_NSPEC] hand-over block, already offset by the column index
   int status, err_layer;
   long long err_step;
   long long step;  // completed steps; i = step + 1
@@ -74,7 +86,9 @@ struct Col {
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
 };
 
+#ifndef LAY
 #define LAY(a, k) c.lay[((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol]
+#endif
 #define STOPC(code, layer)            \
   do {                                \
     if (!c.status) {                  \
@@ -145,6 +159,11 @@ __device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T
   return rc;
 }
 
+// x**3.10 of the permeability law (mo_grav_drain.f90:105, mo_flush.f90:119,128, mo_flood.f90:73) as exp(3.1*log(x)):
+// within ~4e-15 relative of the correctly rounded pow() the reference links (|3.1*log x| <= 22 for x <= 1000), at a
+// third of its instructions and without the double-double constant tables that push the layer loops into spills.
+__device__ __forceinline__ double pow_3p1(double x) { return exp(3.10 * log(x)); }
+
 // func_density, mo_functions.f90:51-62
 __device__ double func_density(double T, double S) {
   double density_0 = 999.842594 + 6.8 / 100.0 * T;
@@ -195,6 +214,12 @@ __device__ __forceinline__ double time_input(int k) { return ((double)(float)k -
 
 struct Ctx {
   const DevParams *p;
+  // The data pointers are taken from DIRECT kernel arguments, not from the parameter block: only then does the compiler
+  // know they are global-memory pointers (global_load/global_store with scalar base) instead of generic flat ones.
+  const double *f_sw, *f_lw, *f_T2m, *f_precip;
+  double *out_lay, *out_scal;
+  int32_t *out_n_active;
+  long long out_col0, out_ncols;
   Salt salt;
   double p17, p14, tf_c3;
 };
@@ -202,14 +227,14 @@ struct Ctx {
 // ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
 // O(N): one pass for the column totals, one pass for the waterline search with prefix sums (the reference
 // recomputes the suffix sums for every candidate layer).
-__device__ double func_freeboard(Col &c, const Ctx &x) {
+__device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
   double snowmass = (x.p->cfg.freeboard_snow_flag == 0) ? c.m_snow : 0.0;
   double A = 0.0, G = 0.0;
   for (int k = 1; k <= Na; ++k) {
     double th = LAY(SAMSIM_A_THICK, k);
-    A += LAY(SAMSIM_A_PSI_S, k) * th;
-    G += LAY(SAMSIM_A_PSI_G, k) * th;
+    A += LAY(c.ps, k) * th;
+    G += LAY(c.pg, k) * th;
   }
   double buoy = A * (rho_l - rho_s) + G * rho_l;
   double freeboard;
@@ -223,7 +248,7 @@ __device__ double func_freeboard(Col &c, const Ctx &x) {
       ++k;
       mk = LAY(SAMSIM_A_M, k);
       thk = LAY(SAMSIM_A_THICK, k);
-      double a = LAY(SAMSIM_A_PSI_S, k) * thk, g = LAY(SAMSIM_A_PSI_G, k) * thk;
+      double a = LAY(c.ps, k) * thk, g = LAY(c.pg, k) * thk;
       // buoyancy of the layers below k, mass of layers 1..k
       test2 = (k == Na) ? 0.0 : ((A - (Ap + a)) * (rho_l - rho_s) + (G - (Gp + g)) * rho_l);
       double test1 = (Mp + mk) + snowmass;
@@ -241,7 +266,7 @@ __device__ double func_freeboard(Col &c, const Ctx &x) {
 // ---------------------------------------------------------------- snow, mo_snow.f90
 // snow_coupling, mo_snow.f90:61-104.  The reference passes T_snow / T as both the guess and the result of getT;
 // by-reference argument passing makes the guess H/c_l (getT's first statement overwrites it).
-__device__ void snow_coupling(Col &c, const Ctx &x) {
+__device__ RARE void snow_coupling(Col &c, const Ctx &x) {
   const Salt &s = x.salt;
   double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), S_bu = LAY(SAMSIM_A_S_BU, 1);
   double T = LAY(SAMSIM_A_T, 1), phi = LAY(SAMSIM_A_PHI, 1), H;
@@ -315,7 +340,7 @@ __device__ void snow_fall(Col &c, const Ctx &x) {
 
 // snow_thermo (mo_snow.f90:212-320) / snow_thermo_meltwater (:331-454) wrapped in the block of
 // mo_grotz.f90:273-292 and :604-624
-__device__ void snow_block(Col &c, const Ctx &x) {
+__device__ RARE void snow_block(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   if (!(c.thick_snow > 0.0)) {
     c.thick_snow = 0.0; c.m_snow = 0.0; c.psi_s_snow = 0.0; c.psi_l_snow = 0.0; c.psi_g_snow = 0.0;
@@ -410,16 +435,74 @@ __device__ void snow_block(Col &c, const Ctx &x) {
 // ---------------------------------------------------------------- S1: first thermodynamic sweep, bottom -> top
 // mo_grotz.f90:297-307 (S_bu, H, getT chain, S_br, Expulsion mo_thermo_functions.f90:157-187) fused with the
 // permeability / Rayleigh-number part of fl_grav_drain (mo_grav_drain.f90:103-136): ray(k) needs only suffix
-// quantities over k..N_active, which this sweep meets in the right order.
-__device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
+// quantities over k..N_active, which an upward sweep meets in the right order.
+//
+// RayScan carries those suffix quantities; s1_layer is the per-layer body shared by
+//   - sweep_thermo_expulsion  the full sweep (first step, and after flushing / regridding changed the column),
+//   - sweep_up_fused          which runs it for layers N_active..2 of the NEXT step right after the second getT of
+//                             this step (same enthalpy, same guess chain => the same T and phi, computed once),
+//   - prologue_top_layer      layer 1 of the current step (everything that changes between two steps touches layer 1).
+struct RayScan {
+  double minp, stp, st;                      // suffix min(perm), sum(thick/perm), sum(thick) over k..Na-1
+  double bot, botterm, perm_bot, S_br_bot;   // bottom layer (enters linearly, mo_grav_drain.f90:119-120,128)
+  double buoy_s, min_psi_s;                  // SUM(psi_s*thick), MIN(psi_s)
+};
+__device__ __forceinline__ void ray_scan_init(RayScan &r) {
+  r.minp = 1.0e300; r.stp = 0.0; r.st = 0.0; r.bot = 0.0; r.botterm = 0.0; r.perm_bot = 0.0; r.S_br_bot = 0.0;
+  r.buoy_s = 0.0; r.min_psi_s = 1.0e300;
+}
+
+// Expulsion + permeability + Rayleigh number of layer k given its T, phi; writes psi_* into buffers (ps,pl,pg), V_ex, ray
+__device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bool do_ray, double T, double phi, double S_bu,
+                                         double m, double thick, int ps, int pl, int pg, RayScan &r) {
+  const samsim_config &g = x.p->cfg;
+  const double S_br = S_br_clamped(x.salt, T, S_bu);
+  const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
+  double V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
+  double psi_s = V_s / thick, psi_l = (V_l - V_ex) / thick, psi_g = (thick - V_l - V_s + V_ex) / thick;
+  if (psi_l < 0.0) psi_l = 0.0;
+  if (psi_g < 0.0) psi_g = 0.0;
+  r.min_psi_s = dmin(r.min_psi_s, psi_s);
+  r.buoy_s += psi_s * thick;
+  LAY(ps, k) = psi_s;
+  LAY(pl, k) = psi_l;
+  LAY(pg, k) = psi_g;
+  LAY(D_V_EX, k) = V_ex;
+  if (do_ray) {
+    const double perm = x.p17 * pow_3p1(1000.0 * fabs(psi_l));  // mo_grav_drain.f90:105
+    if (k == Na) {
+      r.S_br_bot = S_br;
+      r.bot = thick * psi_s / psi_s_min;
+      r.perm_bot = perm;
+      r.botterm = r.bot / perm;
+    } else {
+      const double height = r.st + r.bot;  // thick(k+1..Na-1) + bottom part
+      r.minp = dmin(r.minp, perm);
+      r.stp = r.stp + thick / perm;
+      r.st = r.st + thick;
+      double ray;
+      const double d_S_br = S_br - r.S_br_bot;
+      if (g.harmonic_flag == 2) {
+        const double hp = (r.minp < x.p14) ? 0.0 : (r.st + r.bot) / (r.stp + r.botterm);
+        ray = grav_f * rho_l * bbeta * d_S_br * height * hp;
+      } else {
+        ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(r.minp, r.perm_bot);
+      }
+      ray = ray / (kappa_l * mu);
+      ray = dmax(ray, 0.0);
+      LAY(SAMSIM_A_RAY, k) = ray;
+    }
+  }
+}
+
+__device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
   const bool do_ray = (g.grav_flag == 2 && Na > 1);
   double T_test = g.T_bottom;
-  double minp = 1.0e300, stp = 0.0, st = 0.0;  // suffix min(perm), sum(thick/perm), sum(thick) over k..Na-1
-  double S_br_bot = 0.0, bot = 0.0, botterm = 0.0, perm_bot = 0.0;
-  double min_psi_s = 1.0e300, buoy_s = 0.0;
+  RayScan r;
+  ray_scan_init(r);
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   for (int k = Na; k >= 1; --k) {
@@ -431,62 +514,49 @@ __device__ void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     }
     const double S_bu = S_abs / m, H = H_abs / m;
     double T, phi = 0.0;
-    int r = getT(s, H, S_bu, T_test, T, phi);
-    if (r && !rc) { rc = r; rc_layer = k; }
+    int rr = getT(s, H, S_bu, T_test, T, phi);
+    if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
-    const double S_br = S_br_clamped(s, T, S_bu);
-    // Expulsion
-    const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
-    double V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
-    double psi_s = V_s / thick, psi_l = (V_l - V_ex) / thick, psi_g = (thick - V_l - V_s + V_ex) / thick;
-    if (psi_l < 0.0) psi_l = 0.0;
-    if (psi_g < 0.0) psi_g = 0.0;
-    min_psi_s = dmin(min_psi_s, psi_s);
-    buoy_s += psi_s * thick;
-    // phi is not stored: the second sweep rewrites it before anything reads it.  S_bu is not stored either: the
-    // only reader before the refresh in P2 is mass_transfer's func_S_br(T, S_bu), which equals S_br bit for bit.
+    // phi is not stored: the second sweep rewrites it before anything reads it.  S_bu / S_br are not stored either:
+    // their only readers recompute them from T, S_abs, m (see sweep_expulsion_transfer, sweep_down_fused).
     LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_S_BR, k) = S_br;
-    LAY(SAMSIM_A_PSI_S, k) = psi_s;
-    LAY(SAMSIM_A_PSI_L, k) = psi_l;
-    LAY(SAMSIM_A_PSI_G, k) = psi_g;
-    LAY(D_V_EX, k) = V_ex;
-    if (do_ray) {
-      const double perm = x.p17 * pow(1000.0 * fabs(psi_l), 3.10);  // mo_grav_drain.f90:105
-      if (k == Na) {
-        S_br_bot = S_br;
-        bot = thick * psi_s / psi_s_min;  // bottom layer enters linearly
-        perm_bot = perm;
-        botterm = bot / perm;
-      } else {
-        const double height = st + bot;  // thick(k+1..Na-1) + bottom part
-        minp = dmin(minp, perm);
-        stp = stp + thick / perm;
-        st = st + thick;
-        double ray;
-        const double d_S_br = S_br - S_br_bot;
-        if (g.harmonic_flag == 2) {
-          double hp = (minp < x.p14) ? 0.0 : (st + bot) / (stp + botterm);
-          ray = grav_f * rho_l * bbeta * d_S_br * height * hp;
-        } else {
-          ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(minp, perm_bot);
-        }
-        ray = ray / (kappa_l * mu);
-        ray = dmax(ray, 0.0);
-        LAY(SAMSIM_A_RAY, k) = ray;
-      }
-    }
+    s1_layer(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, c.ps, c.pl, c.pg, r);
   }
-  c.min_psi_s = min_psi_s;
-  c.buoy_s = buoy_s;
+  c.min_psi_s = r.min_psi_s;
+  c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, rc_layer);
+}
+
+// Layer 1 of the first sweep when layers N_active..2 were already done by the previous step's up sweep
+// (their prognostic values have not changed since).  The scan state comes from the hand-over block.
+__device__ void prologue_top_layer(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  const size_t nc = c.ncol;
+  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  RayScan r;
+  r.minp = c.spec[SP_MINP * nc]; r.stp = c.spec[SP_STP * nc]; r.st = c.spec[SP_ST * nc];
+  r.bot = c.spec[SP_BOT * nc]; r.botterm = c.spec[SP_BOTTERM * nc]; r.perm_bot = c.spec[SP_PERM_BOT * nc];
+  r.S_br_bot = c.spec[SP_SBR_BOT * nc]; r.buoy_s = c.spec[SP_BUOY_S * nc]; r.min_psi_s = c.spec[SP_MIN_PSI_S * nc];
+  const double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1);
+  double S_abs = LAY(SAMSIM_A_S_ABS, 1);
+  if (S_abs < 0.0) { S_abs = 0.0; LAY(SAMSIM_A_S_ABS, 1) = S_abs; }
+  const double S_bu = S_abs / m, H = H_abs / m;
+  const double T_test = (Na > 1) ? LAY(SAMSIM_A_T, 2) : g.T_bottom;
+  double T, phi = 0.0;
+  const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
+  LAY(SAMSIM_A_T, 1) = T;
+  s1_layer(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, c.ps, c.pl, c.pg, r);
+  c.min_psi_s = r.min_psi_s;
+  c.buoy_s = r.buoy_s;
+  if (rc) STOPC(rc, 1);
 }
 
 // ---------------------------------------------------------------- P2: expulsion_flux + mass_transfer, top -> bottom
 // expulsion_flux (mo_mass.f90:112-136): downward brine flux recurrence, m and psi_g update.  mass_transfer
 // (mo_mass.f90:53-96) with these fluxes (all <= 0: brine only moves down) needs the layer above only.  Then the
 // S_bu refresh of mo_grotz.f90:333-335.  mass_transfer is skipped on the first step (mo_grotz.f90:313).
-__device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
+__device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   const int Na = c.Na;
   const bool transfer = (c.step + 1 != 1);
   double flm_k = 0.0;  // fl_m(k)
@@ -496,7 +566,7 @@ __device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     const double V_ex = LAY(D_V_EX, k);
     double m = LAY(SAMSIM_A_M, k);
     double flm_next;
-    double psi_g = LAY(SAMSIM_A_PSI_G, k);
+    double psi_g = LAY(c.pg, k);
     if (k == 1) {
       flm_next = -V_ex * rho_l;
       if (psi_g > 0.0) buoy_g += psi_g * LAY(SAMSIM_A_THICK, k);
@@ -507,17 +577,18 @@ __device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
       const double thick = LAY(SAMSIM_A_THICK, k);
       flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
       psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
-      LAY(SAMSIM_A_PSI_G, k) = psi_g;
+      LAY(c.pg, k) = psi_g;
       buoy_g += psi_g * thick;
     }
+    const double m_in = m;
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
     double S_abs = LAY(SAMSIM_A_S_ABS, k);
-    double T = 0.0, S_br = 0.0;
-    if (transfer && (flm_next < 0.0 || flm_k < 0.0)) {
-      T = LAY(SAMSIM_A_T, k);
-      S_br = LAY(SAMSIM_A_S_BR, k);  // == func_S_br(TT(k), SS_bu(k)) of mo_mass.f90:85
-    }
+    // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
+    // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
+    const double T = LAY(SAMSIM_A_T, k);
+    const double S_br = S_br_clamped(x.salt, T, S_abs / m_in);
+    LAY(SAMSIM_A_S_BR, k) = S_br;
     if (transfer) {
       double H_abs = 0.0;
       bool ch = false;
@@ -545,20 +616,22 @@ __device__ void sweep_expulsion_transfer(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- vital signs, mo_grotz.f90:192-223 (output only)
-__device__ void vital_signs(Col &c, const Ctx &x) {
+__device__ RARE void vital_signs(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
+  // the reference evaluates these at the top of the loop with the PREVIOUS step's volume fractions: those sit in the
+  // buffer that was current during the previous step (nps/npl); ps/pl already hold this step's layers >= 2
   double sH = 0.0, sm = 0.0, sS = 0.0, resist = 0.0, sth = 0.0, sS1 = 0.0, sm1 = 0.0;
   for (int k = 1; k <= Na; ++k) {
     const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
     sH += H_abs; sm += m; sS += S_abs;
     if (k <= Na - 1) {
       const double thick = LAY(SAMSIM_A_THICK, k);
-      resist = resist + thick / (LAY(SAMSIM_A_PSI_L, k) * k_l + LAY(SAMSIM_A_PSI_S, k) * k_s);
+      resist = resist + thick / (LAY(c.npl, k) * k_l + LAY(c.nps, k) * k_s);
       sth += thick; sS1 += S_abs; sm1 += m;
     }
   }
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.nps, Na);
   c.energy_stored = c.H_abs_snow + sH - g.T_bottom * sm * c_l;
   c.freshwater = sm / rho_l;
   c.freshwater = c.freshwater * (1.0 - sS / sm / ref_salinity);
@@ -576,18 +649,18 @@ __device__ void vital_signs(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- flood, mo_flood.f90:55-151
-__device__ void flood(Col &c, const Ctx &x) {
+__device__ RARE void flood(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   double hp = 0.0, sth = 0.0;
   for (int k = 1; k <= Na - 1; ++k) {
     const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow(1000.0 * LAY(SAMSIM_A_PSI_L, k), 3.10);
+    const double perm = x.p17 * pow_3p1(1000.0 * LAY(c.pl, k));
     hp = hp + thick / perm;
     sth += thick;
   }
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
-  const double permN = x.p17 * pow(1000.0 * LAY(SAMSIM_A_PSI_L, Na), 3.10);
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.ps, Na);
+  const double permN = x.p17 * pow_3p1(1000.0 * LAY(c.pl, Na));
   hp = hp + (thN * psN / psi_s_min) / permN;
   hp = (sth + thN * psN / psi_s_min) / hp;
   const double sall = sth + thN;
@@ -635,17 +708,17 @@ __device__ void flood(Col &c, const Ctx &x) {
 }
 
 // recompute ray(1) after flood changed thick(1) (thick(1) enters only the k = 1 harmonic mean)
-__device__ void refresh_ray_top(Col &c, const Ctx &x) {
+__device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   if (g.harmonic_flag != 2) return;  // MINVAL variant does not depend on thick(1)
   double minp = 1.0e300, stp = 0.0, st = 0.0, height = 0.0;
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.ps, Na);
   const double bot = thN * psN / psi_s_min;
-  const double botterm = bot / (x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, Na)), 3.10));
+  const double botterm = bot / (x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, Na))));
   for (int k = Na - 1; k >= 1; --k) {
     const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)), 3.10);
+    const double perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k)));
     height = st + bot;
     minp = dmin(minp, perm);
     stp = stp + thick / perm;
@@ -663,7 +736,7 @@ __device__ void refresh_ray_top(Col &c, const Ctx &x) {
 // (mo_mass.f90:53-96) with fl_m(k+1) = fl_up(k) >= 0.  mass_transfer reads the salt of the layer BELOW after the
 // drainage loop (snapshot SS_abs), so layer k+1 is drained one iteration ahead of the transfer into layer k.
 // The same pass multiplies up the Beer-law transmittance for fl_rad(N_active) (mo_heat_fluxes.f90:151-155).
-__device__ void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer0) {
+__device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer0) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -697,9 +770,9 @@ __device__ void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer
       S_br_j = LAY(SAMSIM_A_S_BR, j + 1);
       const double ray = LAY(SAMSIM_A_RAY, j);
       if (ray > ray_crit && S_br > S_br_j) {
-        const double psi_s = LAY(SAMSIM_A_PSI_S, j), m = LAY(SAMSIM_A_M, j);
+        const double psi_s = LAY(c.ps, j), m = LAY(SAMSIM_A_M, j);
         if (psi_s > 0.001 && r.S_abs / m > 0.1) {
-          const double psi_l = LAY(SAMSIM_A_PSI_L, j);
+          const double psi_l = LAY(c.pl, j);
           double flux = x_grav * (ray - ray_crit) * dt * thick;
           flux = dmin(flux, psi_l * rho_l * thick);
           r.S_abs = r.S_abs - flux * S_br;
@@ -756,7 +829,7 @@ __device__ void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer
 }
 
 // Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
-__device__ void sweep_beer(Col &c, double beer0) {
+__device__ RARE void sweep_beer(Col &c, double beer0) {
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
   for (int k = 1; k <= Na; ++k) {
@@ -767,21 +840,161 @@ __device__ void sweep_beer(Col &c, double beer0) {
   }
 }
 
+// ---------------------------------------------------------------- D: fused down sweep (P2 + P3), top -> bottom
+// One pass instead of two for the common step (not the first, not an output step, no thin-snow coupling, no flooding):
+// per layer j   A(j) expulsion_flux + mass_transfer + S_bu refresh          (mo_mass.f90:112-136, 53-96; mo_grotz.f90:333)
+//               [j = N_active: gas -> ocean water, bottom turbulence]        (mo_grotz.f90:405-410, 450-457)
+//               B(j) gravity-drainage loss of layer j, fl_up(j)              (mo_grav_drain.f90:144-170)
+//               C(j-1) return-flow mass_transfer into layer j-1, final store (mo_grav_drain.f90:174-193)
+// A(j) of the reference runs for all layers before B starts, but A(j) only reads layers <= j and B/C(j-1) only layers
+// j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
+// T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
+__device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const double dt = g.dt;
+  double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300, buoy_g = 0.0;
+  double temp2 = beer0, e = 0.0, th_prev = -1.0;
+  int stop_layer = 0;
+
+  struct Raw { double T, S_abs, m, S_br; };
+  auto load_raw = [&](int j) -> Raw {
+    Raw r;
+    r.T = LAY(SAMSIM_A_T, j);
+    r.S_abs = LAY(SAMSIM_A_S_ABS, j);
+    r.m = LAY(SAMSIM_A_M, j);
+    r.S_br = S_br_clamped(s, r.T, r.S_abs / r.m);  // S_br(j) of the first sweep
+    return r;
+  };
+  struct Lay { double T, S_bu, S_abs, H_abs, m, flup; };
+
+  double flm_j = 0.0;                                  // fl_m(j) of expulsion_flux
+  double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
+  Raw raw = load_raw(1), raw_n = raw;
+  Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
+  double flup_pp = 0.0;                                // fl_up(j-2)
+  for (int j = 1; j <= Na; ++j) {
+    if (j < Na) raw_n = load_raw(j + 1);
+    // ---- A(j)
+    const double V_ex = LAY(D_V_EX, j), thick = LAY(SAMSIM_A_THICK, j);
+    double psi_g = LAY(c.pg, j), m = raw.m, S_abs = raw.S_abs, H_abs = LAY(SAMSIM_A_H_ABS, j);
+    const double T = raw.T, S_br = raw.S_br;
+    if (do_beer) {
+      if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
+      if (j == Na) c.frad = temp2 - temp2 * e;
+      temp2 = temp2 * e;
+    }
+    double flm_next;
+    if (j == 1 || psi_g < (double)0.001f) {
+      flm_next = (j == 1) ? -V_ex * rho_l : -V_ex * rho_l + flm_j;
+    } else {
+      flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
+      psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
+      LAY(c.pg, j) = psi_g;
+    }
+    if (psi_g > 0.0) buoy_g += psi_g * thick;
+    m = m + flm_next - flm_j;
+    if (flm_next < 0.0) {
+      H_abs = H_abs + flm_next * T * c_l;
+      S_abs = S_abs + dmax(flm_next * S_br, -S_abs);
+    }
+    if (flm_j < 0.0) {
+      H_abs = H_abs - flm_j * T_up * c_l;
+      S_abs = S_abs - dmax(flm_j * S_br_up, -S_abs_up);
+    }
+    const double S_bu = S_abs / m;  // refreshed bulk salinity, mo_grotz.f90:333-335
+    T_up = T; S_br_up = S_br; S_abs_up = S_abs;
+    flm_j = flm_next;
+    if (j == Na) {
+      if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
+        const double t2 = psi_g * thick * rho_l;
+        m = m + t2;
+        S_abs = S_abs + t2 * g.S_bu_bottom;
+        H_abs = H_abs + t2 * c_l * g.T_bottom;
+      }
+      if (g.turb_flag == 2) {  // sub_turb_flux
+        const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * dt;
+        S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+      }
+    }
+    // ---- B(j)
+    sum_before += S_abs;
+    double flup = cum;
+    if (j <= Na - 1) {
+      const double ray = LAY(SAMSIM_A_RAY, j);
+      if (ray > ray_crit && S_br > raw_n.S_br) {
+        const double psi_s = LAY(c.ps, j);
+        if (psi_s > 0.001 && S_abs / m > 0.1) {
+          const double psi_l = LAY(c.pl, j);
+          double flux = x_grav * (ray - ray_crit) * dt * thick;
+          flux = dmin(flux, psi_l * rho_l * thick);
+          S_abs = S_abs - flux * S_br;
+          if (S_abs < 0.0 && !stop_layer) stop_layer = j;
+          c.grav_temp = c.grav_temp + flux * T;
+          H_abs = H_abs - flux * c_l * T;
+          heat_loss = heat_loss + flux * c_l * T;
+          cum = cum + flux;
+          flup = dmin(cum, psi_l * rho_l * thick);
+        }
+      }
+    }
+    sum_after += S_abs;
+    // ---- C(j-1): layer j-1 receives from layer j (fl_m(j) = fl_up(j-1)) and gives to j-2 (fl_m(j-1) = fl_up(j-2))
+    if (j > 1) {
+      if (prev.flup > 0.0) {
+        prev.H_abs = prev.H_abs + prev.flup * T * c_l;
+        prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, T, S_bu), S_abs);
+      }
+      if (flup_pp > 0.0) {
+        prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
+        prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
+      }
+      LAY(SAMSIM_A_M, j - 1) = prev.m;
+      LAY(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
+      LAY(SAMSIM_A_H_ABS, j - 1) = prev.H_abs;
+      minS = dmin(minS, prev.S_abs);
+      flup_pp = prev.flup;
+    }
+    prev.T = T; prev.S_bu = S_bu; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
+    raw = raw_n;
+  }
+  // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
+  if (prev.flup > 0.0) {
+    prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
+    prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, g.T_bottom, g.S_bu_bottom), g.S_bu_bottom * 2000.0);
+  }
+  if (flup_pp > 0.0) {
+    prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
+    prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
+  }
+  c.grav_drain = c.grav_drain + prev.flup;
+  if (g.grav_heat_flag == 2) prev.H_abs = prev.H_abs + heat_loss - prev.flup * c_l * g.T_bottom;
+  LAY(SAMSIM_A_M, Na) = prev.m;
+  LAY(SAMSIM_A_S_ABS, Na) = prev.S_abs;
+  LAY(SAMSIM_A_H_ABS, Na) = prev.H_abs;
+  minS = dmin(minS, prev.S_abs);
+  c.buoy_g = buoy_g;
+  c.grav_salt = c.grav_salt + sum_before;
+  c.grav_salt = c.grav_salt - sum_after;
+  if (stop_layer) STOPC(21234, stop_layer);
+  if (minS < 0.0) STOPC(1337, 0);
+}
+
 // ---------------------------------------------------------------- surface energy balance, mo_heat_fluxes.f90:77-195
 // sets fl_Q(1), T_top, fl_Q_snow, albedo, fl_sw, fl_lw, T_freeze; returns the Beer-law surface value temp2
 __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (g.boundflux_flag != 2) return 0.0;
-  const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1);
+  const double psi_l1 = LAY(c.pl, 1);
   c.albedo = func_albedo(c.thick_snow, c.T_snow, psi_l1, g.thick_min, g.albedo_flag);
-  const DevParams *p = x.p;
   if (time == time_input(tc)) {
-    c.fl_sw = p->f_sw[tc - 1];
-    c.fl_lw = p->f_lw[tc - 1];
+    c.fl_sw = x.f_sw[tc - 1];
+    c.fl_lw = x.f_lw[tc - 1];
   } else {
     const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-    c.fl_sw = (1.0 - temp) * p->f_sw[tc - 2] + temp * p->f_sw[tc - 1];
-    c.fl_lw = (1.0 - temp) * p->f_lw[tc - 2] + temp * p->f_lw[tc - 1];
+    c.fl_sw = (1.0 - temp) * x.f_sw[tc - 2] + temp * x.f_sw[tc - 1];
+    c.fl_lw = (1.0 - temp) * x.f_lw[tc - 2] + temp * x.f_lw[tc - 1];
   }
   const double pen = (c.thick_snow < g.thick_min) ? penetr : 0.0;
   return pen * (1.0 - c.albedo) * c.fl_sw;
@@ -790,7 +1003,7 @@ __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
 __device__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
-  const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
+  const double psi_s1 = LAY(c.ps, 1), psi_l1 = LAY(c.pl, 1), psi_g1 = LAY(c.pg, 1);
   const double thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   const double k1 = psi_s1 * k_s + psi_l1 * k_l + psi_g1 * 0.0;
   if (g.boundflux_flag == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
@@ -863,13 +1076,13 @@ __device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
   // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
-  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
+  double kk_k = LAY(c.ps, Na) * k_s + LAY(c.pl, Na) * k_l;
   for (int k = Na; k >= 1; --k) {
     double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
+      kk_u = LAY(c.ps, k - 1) * k_s + LAY(c.pl, k - 1) * k_l;
       const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
@@ -914,6 +1127,102 @@ __device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
   if (fabs((temp1 - temp2) / dt) > 0.00001) STOPC(431, 0);
 }
 
+// ---------------------------------------------------------------- U: fused up sweep (P4 + next step's S1), bottom -> top
+// sweep_heat_thermo plus, for layers N_active..2, the first sweep of the NEXT time step: that sweep would divide the
+// same H_abs by the same m and start Newton from the same guesses (T_bottom, then the layer below), so its T and phi
+// are exactly the ones just computed.  What it adds -- S_br, Expulsion, permeability, Rayleigh number -- is done here
+// from registers and written to the NEXT psi buffers (nps/npl/npg), because this step's remaining readers (melt film,
+// freeboard, flush3) still need the current ones.  Layer 1 is left to prologue_top_layer: snow, melt water and the
+// regrid trigger all act on it between the two steps.  If flushing or a regrid changes deeper layers afterwards, the
+// column is flagged COLF_DIRTY and the next step runs the full first sweep instead.
+__device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output) {
+  const samsim_config &g = x.p->cfg;
+  const Salt &s = x.salt;
+  const int Na = c.Na;
+  const size_t nc = c.ncol;
+  const double dt = g.dt, thick_min = g.thick_min;
+  const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
+  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  const bool keep_ray = next_is_output && col >= x.out_col0 && col < x.out_col0 + x.out_ncols;
+  const double H_abs_snow_before = c.H_abs_snow;
+  double sum_before = 0.0, sum_after = 0.0;
+  double flq_below = c.fl_q_bottom;  // fl_Q(k+1)
+  double T_test = g.T_bottom;
+  int rc = 0, rc_layer = 0;
+  RayScan r;
+  ray_scan_init(r);
+  if (keep_ray) {  // `output` prints the Rayleigh numbers of THIS step's fl_grav_drain at the next step's output point
+    const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
+    for (int k = 1; k <= c.N - 1; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * c.N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
+  }
+  if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
+  // layer k (old values)
+  double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
+  double kk_k = LAY(c.ps, Na) * k_s + LAY(c.pl, Na) * k_l;
+  for (int k = Na; k >= 1; --k) {
+    double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
+    if (k > 1) {
+      T_u = LAY(SAMSIM_A_T, k - 1);
+      th_u = LAY(SAMSIM_A_THICK, k - 1);
+      kk_u = LAY(c.ps, k - 1) * k_s + LAY(c.pl, k - 1) * k_l;
+      const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
+      flq_k = (T_k - T_u) / R;
+    } else {
+      flq_k = c.fl_Q1;
+    }
+    double H_abs = LAY(SAMSIM_A_H_ABS, k);
+    sum_before += H_abs;
+    H_abs = H_abs + (flq_below - flq_k) * dt;
+    H_abs = H_abs + c.frad * dt;
+    const double m = LAY(SAMSIM_A_M, k);
+    if (k == 1) {  // snow treatment, mo_heat_fluxes.f90:291-303
+      if (thin_snow) {
+        c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
+        LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+        snow_coupling(c, x);
+        if (c.status) return;
+        H_abs = LAY(SAMSIM_A_H_ABS, 1);
+      } else if (c.thick_snow >= thick_min) {
+        c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
+      }
+    }
+    sum_after += H_abs;
+    LAY(SAMSIM_A_H_ABS, k) = H_abs;
+    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const double S_bu = S_abs / m, H = H_abs / m;
+    double T, phi = 0.0;
+    int rr = getT(s, H, S_bu, T_test, T, phi);
+    if (rr && !rc) { rc = rr; rc_layer = k; }
+    T_test = T;
+    LAY(SAMSIM_A_T, k) = T;
+    LAY(SAMSIM_A_PHI, k) = phi;
+    LAY(SAMSIM_A_S_BU, k) = S_bu;
+    if (k > 1) {
+      // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
+      double S_bu_n = S_bu;
+      if (S_abs < 0.0) {
+        // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
+        c.flags |= COLF_DIRTY;
+      }
+      s1_layer(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, c.nps, c.npl, c.npg, r);
+    }
+    flq_below = flq_k;
+    T_k = T_u; th_k = th_u; kk_k = kk_u;
+  }
+  // hand-over block for prologue_top_layer of the next step
+  c.spec[SP_MINP * nc] = r.minp; c.spec[SP_STP * nc] = r.stp; c.spec[SP_ST * nc] = r.st;
+  c.spec[SP_BOT * nc] = r.bot; c.spec[SP_BOTTERM * nc] = r.botterm; c.spec[SP_PERM_BOT * nc] = r.perm_bot;
+  c.spec[SP_SBR_BOT * nc] = r.S_br_bot; c.spec[SP_BUOY_S * nc] = r.buoy_s; c.spec[SP_MIN_PSI_S * nc] = r.min_psi_s;
+  // energy conservation assert, mo_heat_fluxes.f90:265-310
+  double temp1 = sum_before + H_abs_snow_before;
+  temp1 = temp1 + (double)Na * (c.frad * dt);
+  if (thin_snow || c.thick_snow >= thick_min) temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
+  else temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q1 * dt;
+  const double temp2 = sum_after + c.H_abs_snow;
+  if (rc) STOPC(rc, rc_layer);
+  if (fabs((temp1 - temp2) / dt) > 0.00001) STOPC(431, 0);
+}
+
 // ---------------------------------------------------------------- melt film, mo_functions.f90:386-474
 __device__ void sub_melt_thick(double psi_l, double psi_s, double psi_g, double T, double T_freeze, double T_top, double fl_Q,
                                double thick_snow, double dt, double &melt_thick, double &thick, double thick_min) {
@@ -936,7 +1245,7 @@ __device__ void sub_melt_thick(double psi_l, double psi_s, double psi_g, double 
 }
 
 // ---------------------------------------------------------------- flush3, mo_flush.f90:70-237
-__device__ void flush3(Col &c, const Ctx &x) {
+__device__ RARE void flush3(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na, N = c.N;
@@ -945,7 +1254,7 @@ __device__ void flush3(Col &c, const Ctx &x) {
   double cnst = 0.0;
   for (int k = 1; k <= Na; ++k) cnst += LAY(SAMSIM_A_THICK, k);
   cnst = cnst * para_flush_horiz;
-  const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
+  const double psi_l1 = LAY(c.pl, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   c.melt_thick = dmin(c.melt_thick, psi_l1 * thick1);
   c.melt_thick = dmin(c.melt_thick, g.thick_0 / 3.0);
 
@@ -957,10 +1266,10 @@ __device__ void flush3(Col &c, const Ctx &x) {
     const double thick = LAY(SAMSIM_A_THICK, k);
     double perm;
     if (g.snow_flush_flag == 1) {
-      perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k) + 2.0 * LAY(SAMSIM_A_PSI_G, k)), 3.10);
+      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k) + 2.0 * LAY(c.pg, k)));
       if (perm == 0.0) perm = 1.0;
     } else {
-      perm = x.p17 * pow(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)), 3.10);
+      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k)));
     }
     LAY(SAMSIM_A_PERM, k) = perm;
     const double pm = dmax(perm, 0.00000000000000000000001);
@@ -1212,7 +1521,7 @@ __device__ void bottom_growth(Col &c, const Ctx &x) {
 }
 
 // layer_dynamics, mo_layer_dynamics.f90:64-175: exactly one branch per call, in priority order
-__device__ void layer_dynamics(Col &c, const Ctx &x) {
+__device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, Na = c.Na, N_top = g.n_top, bf = g.bottom_flag;
   const double thick_0 = g.thick_0;
@@ -1249,21 +1558,26 @@ __device__ void layer_dynamics(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- output snapshot, mo_grotz.f90:340-398
-__device__ void output_point(Col &c, const Ctx &x, long long col, double time) {
+__device__ RARE void output_point(Col &c, const Ctx &x, long long col, double time) {
   const samsim_config &g = x.p->cfg;
-  const DevParams *p = x.p;
   if (c.Na > 1) c.freeboard = func_freeboard(c, x); else c.freeboard = 0.0;
   if (g.grav_flag == 2) {
     if (c.grav_drain == 0.0) c.grav_temp = 0.0; else c.grav_temp = c.grav_temp / c.grav_drain;
     c.grav_salt = c.grav_salt / g.time_out;
     c.grav_drain = c.grav_drain / g.time_out;
   }
-  if (col >= p->out_col0 && col < p->out_col0 + p->out_ncols) {
-    const size_t oc = (size_t)(col - p->out_col0), on = (size_t)p->out_ncols;
-    for (int a = 0; a < SAMSIM_NARR; ++a)
-      if (a != SAMSIM_A_RAY)
-        for (int k = 1; k <= c.N; ++k) p->out_lay[((size_t)a * c.N + (k - 1)) * on + oc] = LAY(a, k);
-    double *o = p->out_scal + oc;
+  if (col >= x.out_col0 && col < x.out_col0 + x.out_ncols) {
+    const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
+    for (int a = 0; a < SAMSIM_NARR; ++a) {
+      if (a == SAMSIM_A_RAY) continue;  // captured before it was overwritten (see sweep_up_fused / column_step)
+      const int src = (a == SAMSIM_A_PSI_S) ? c.ps : (a == SAMSIM_A_PSI_L) ? c.pl : (a == SAMSIM_A_PSI_G) ? c.pg : a;
+      for (int k = 1; k <= c.N; ++k) {
+        double v = LAY(src, k);
+        if (a == SAMSIM_A_S_BU && k <= c.Na) v = LAY(SAMSIM_A_S_ABS, k) / LAY(SAMSIM_A_M, k);  // refresh of mo_grotz.f90:333-335
+        x.out_lay[((size_t)a * c.N + (k - 1)) * on + oc] = v;
+      }
+    }
+    double *o = x.out_scal + oc;
 #define OUT(idx, v) o[(size_t)(idx) * on] = (v)
     OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
     OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
@@ -1279,7 +1593,7 @@ __device__ void output_point(Col &c, const Ctx &x, long long col, double time) {
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
     OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
 #undef OUT
-    p->out_n_active[oc] = c.Na;
+    x.out_n_active[oc] = c.Na;
   }
   c.grav_drain = 0.0; c.grav_salt = 0.0; c.grav_temp = 0.0;
   c.melt_out1 = 0.0; c.melt_out2 = 0.0; c.melt_out3 = 0.0;
@@ -1287,29 +1601,29 @@ __device__ void output_point(Col &c, const Ctx &x, long long col, double time) {
 }
 
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
-__device__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step) {
+__device__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
   const samsim_config &g = x.p->cfg;
-  const DevParams *p = x.p;
   const int N = c.N;
 
   if (out_step) {
     vital_signs(c, x);  // mo_grotz.f90:192-223; only ever read by `output`
-    // `output` prints the Rayleigh numbers of the PREVIOUS step's fl_grav_drain; S1 below overwrites them
-    if (col >= p->out_col0 && col < p->out_col0 + p->out_ncols) {
-      const size_t oc = (size_t)(col - p->out_col0), on = (size_t)p->out_ncols;
-      for (int k = 1; k <= N; ++k) p->out_lay[((size_t)SAMSIM_A_RAY * N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
+    // `output` prints the Rayleigh numbers of the PREVIOUS step's fl_grav_drain.  Normally the previous up sweep has
+    // saved them before overwriting; on the first step after set_state the array itself still holds them.
+    if ((c.flags & COLF_RESTART) && col >= x.out_col0 && col < x.out_col0 + x.out_ncols) {
+      const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
+      for (int k = 1; k <= N; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
     }
   }
 
   // forcing, mo_grotz.f90:229-241 (+ ensemble perturbation)
   if (g.atmoflux_flag == 2) {
     if (time == time_input(tc)) {
-      c.T2m = p->f_T2m[tc - 1];
-      c.liquid_precip = p->f_precip[tc - 1];
+      c.T2m = x.f_T2m[tc - 1];
+      c.liquid_precip = x.f_precip[tc - 1];
     } else {
       const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-      c.T2m = (1.0 - temp) * p->f_T2m[tc - 2] + temp * p->f_T2m[tc - 1];
-      c.liquid_precip = (1.0 - temp) * p->f_precip[tc - 2] + temp * p->f_precip[tc - 1];
+      c.T2m = (1.0 - temp) * x.f_T2m[tc - 2] + temp * x.f_T2m[tc - 1];
+      c.liquid_precip = (1.0 - temp) * x.f_precip[tc - 2] + temp * x.f_precip[tc - 1];
     }
     c.T2m = c.T2m + c.dT2m;
     c.liquid_precip = c.liquid_precip * c.precip_scale;
@@ -1319,73 +1633,102 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   snow_block(c, x);                 // mo_grotz.f90:273-292
   if (c.status) return;
 
-  sweep_thermo_expulsion(c, x);     // mo_grotz.f90:297-307 (+ Rayleigh numbers)
+  // first thermodynamic sweep, mo_grotz.f90:297-307 (+ Rayleigh numbers): only layer 1 is left to do unless the
+  // column changed below layer 1 since the last up sweep
+  if (c.flags & COLF_DIRTY) sweep_thermo_expulsion(c, x);
+  else prologue_top_layer(c, x);
+  c.flags = 0;
   if (c.status) return;
-  sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
-
-  if (out_step) output_point(c, x, col, time);  // mo_grotz.f90:340-398
 
   int Na = c.Na;
-  // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
-  {
-    const double psi_gN = LAY(SAMSIM_A_PSI_G, Na);
-    if (psi_gN > 0.0) {
-      const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
-      LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
-      LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
-      LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
+  const bool do_grav = (g.grav_flag == 2 && Na > 1), do_beer = (g.boundflux_flag == 2);
+  // The fused down sweep covers the common step.  The reference's order is kept by the unfused path whenever something
+  // sits between expulsion and gravity drainage: the output block, thin-snow coupling, a possible flooding event
+  // (decided from SUM(psi_g*thick) AFTER expulsion_flux: m_snow above the solid-only buoyancy is treated as possible).
+  const bool coupling = (c.m_snow > 0.0 && c.thick_snow < g.thick_min);
+  const bool flood_possible = (g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0 &&
+                               c.m_snow > c.buoy_s * (rho_l - rho_s));
+  const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible;
+
+  if (fused) {
+    // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
+    // none of which the down sweep changes, so they can run first
+    if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
+      for (int n = 1; n <= 20; ++n) {
+        if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+      }
+    } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
+      c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
     }
-  }
-  // thin-snow coupling, mo_grotz.f90:418-420
-  if (c.m_snow > 0.0 && c.thick_snow < g.thick_min) {
-    snow_coupling(c, x);
+    const double beer0 = radiation_header(c, x, time, tc);
+    c.frad = 0.0;
+    sweep_down_fused(c, x, do_beer, beer0);
     if (c.status) return;
-  }
-  // flooding, mo_grotz.f90:428-445
-  if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
-    // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
-    // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
-    const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
-    if (c.m_snow > buoy) {
-      c.freeboard = (buoy - c.m_snow) / rho_l;
-      if (c.freeboard < 0.0 && g.flood_flag == 2) {
-        flood(c, x);
-        if (g.grav_flag == 2) refresh_ray_top(c, x);
+  } else {
+    sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
+
+    if (out_step) output_point(c, x, col, time);  // mo_grotz.f90:340-398
+
+    // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
+    {
+      const double psi_gN = LAY(c.pg, Na);
+      if (psi_gN > 0.0) {
+        const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
+        LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
+        LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
+        LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
       }
     }
-  }
-  // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
-  if (g.turb_flag == 2) {
-    const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
-    double S_abs = LAY(SAMSIM_A_S_ABS, Na);
-    const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
-    S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
-    LAY(SAMSIM_A_S_ABS, Na) = S_abs;
-  }
-
-  // testcase specifics, mo_grotz.f90:503-565
-  if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
-    for (int n = 1; n <= 20; ++n) {
-      if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+    // thin-snow coupling, mo_grotz.f90:418-420
+    if (coupling) {
+      snow_coupling(c, x);
+      if (c.status) return;
     }
-  } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
-    c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+    // flooding, mo_grotz.f90:428-445
+    if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
+      // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
+      // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
+      const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
+      if (c.m_snow > buoy) {
+        c.freeboard = (buoy - c.m_snow) / rho_l;
+        if (c.freeboard < 0.0 && g.flood_flag == 2) {
+          flood(c, x);
+          if (g.grav_flag == 2) refresh_ray_top(c, x);
+        }
+      }
+    }
+    // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
+    if (g.turb_flag == 2) {
+      const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
+      double S_abs = LAY(SAMSIM_A_S_ABS, Na);
+      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
+      S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+      LAY(SAMSIM_A_S_ABS, Na) = S_abs;
+    }
+
+    // testcase specifics, mo_grotz.f90:503-565
+    if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
+      for (int n = 1; n <= 20; ++n) {
+        if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+      }
+    } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
+      c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+    }
+
+    // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
+    const double beer0 = radiation_header(c, x, time, tc);
+    c.frad = 0.0;
+    if (do_grav) {
+      sweep_grav_drain(c, x, do_beer, beer0);
+      if (c.status) return;
+    } else if (do_beer) {
+      sweep_beer(c, beer0);
+    }
   }
 
-  // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
-  const double beer0 = radiation_header(c, x, time, tc);
-  const bool do_grav = (g.grav_flag == 2 && Na > 1), do_beer = (g.boundflux_flag == 2);
-  c.frad = 0.0;
-  if (do_grav) {
-    sweep_grav_drain(c, x, do_beer, beer0);
-    if (c.status) return;
-  } else if (do_beer) {
-    sweep_beer(c, beer0);
-  }
-
-  // heat fluxes + second thermodynamic sweep, mo_grotz.f90:584-598
+  // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
   surface_flux(c, x);
-  sweep_heat_thermo(c, x);
+  sweep_up_fused(c, x, col, next_out);
   if (c.status) return;
 
   // snow thermodynamics again, mo_grotz.f90:603-625
@@ -1399,7 +1742,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   if (Na > 1 && g.flush_flag > 2 && g.boundflux_flag == 2) {
     c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
     c.melt_thick = 0.0;
-    const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
+    const double psi_s1 = LAY(c.ps, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
       c.freeboard = func_freeboard(c, x);
@@ -1407,7 +1750,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
       if (c.freeboard > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
-        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
+        sub_melt_thick(LAY(c.pl, 1), psi_s1, LAY(c.pg, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
                        c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
         if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
           // sub_melt_snow, mo_functions.f90:443-474
@@ -1458,6 +1801,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     if (c.melt_thick > 0.000000000001) {
       if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation (:717)
       flush3(c, x);
+      c.flags |= COLF_DIRTY;
       if (c.status) return;
     }
   }
@@ -1468,6 +1812,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     if (LAY(SAMSIM_A_PHI, Na) > psi_s_min || LAY(SAMSIM_A_PHI, Na - 1) <= psi_s_min / 2.0 || th1 / g.thick_0 > 1.5 ||
         th1 / g.thick_0 < 0.5) {
       layer_dynamics(c, x);
+      c.flags |= COLF_DIRTY;
       if (c.status) return;
     }
     Na = c.Na;
@@ -1475,12 +1820,13 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     if (Na < N && LAY(SAMSIM_A_THICK, kn) == 0.0) {  // scrub, :772-783
       LAY(SAMSIM_A_T, Na + 1) = g.T_bottom;
       LAY(SAMSIM_A_S_BU, Na + 1) = g.S_bu_bottom;
-      LAY(SAMSIM_A_PSI_L, Na + 1) = 1.0;
-      LAY(SAMSIM_A_PSI_S, Na + 1) = 0.0;
+      LAY(c.pl, Na + 1) = 1.0;
+      LAY(c.ps, Na + 1) = 0.0;
     }
   } else {
     if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
       layer_dynamics(c, x);
+      c.flags |= COLF_DIRTY;
       if (c.status) return;
     }
   }
@@ -1496,27 +1842,40 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
 #ifndef SAMSIM_WAVES
 #define SAMSIM_WAVES 1
 #endif
-__global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel(const DevParams *__restrict__ pp) {
+__global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel(const DevParams *__restrict__ pp, double *__restrict__ lay, double *__restrict__ scal,
+                                                                        double *__restrict__ spec, int32_t *__restrict__ n_active,
+                                                                        int32_t *__restrict__ status, int32_t *__restrict__ err_layer,
+                                                                        long long *__restrict__ err_step, long long *__restrict__ work,
+                                                                        int32_t *__restrict__ flags, const double *__restrict__ f_sw,
+                                                                        const double *__restrict__ f_lw, const double *__restrict__ f_T2m,
+                                                                        const double *__restrict__ f_precip, double *__restrict__ out_lay,
+                                                                        double *__restrict__ out_scal, int32_t *__restrict__ out_n_active) {
   const DevParams &p = *pp;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.ncol) return;
   Ctx x;
   x.p = pp;
+  x.f_sw = f_sw; x.f_lw = f_lw; x.f_T2m = f_T2m; x.f_precip = f_precip;
+  x.out_lay = out_lay; x.out_scal = out_scal; x.out_n_active = out_n_active;
+  x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   if (p.cfg.salt_flag == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
   Col c;
-  c.lay = p.lay + col;
+  c.lay = lay + col;
   c.ncol = (size_t)p.ncol;
   c.N = p.cfg.nlayer;
-  c.Na = p.n_active[col];
-  c.status = p.status[col];
-  c.err_layer = p.err_layer[col];
-  c.err_step = p.err_step[col];
-  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0;
+  c.Na = n_active[col];
+  c.status = status[col];
+  c.err_layer = err_layer[col];
+  c.err_step = err_step[col];
+  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0;
+  c.flags = flags[col];
+  c.spec = spec + col;
+  int cur = p.buf0;
   const size_t nc = (size_t)p.ncol;
-  double *sc = p.scal + col;
+  double *sc = scal + col;
 #define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
   SLOAD(m_snow, SAMSIM_S_M_SNOW); SLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SLOAD(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SLOAD(thick_snow, SAMSIM_S_THICK_SNOW); SLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SLOAD(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
@@ -1537,28 +1896,33 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   double time = p.time0;
   long long step = p.step0;
   int n_time_out = p.n_time_out0, tc = p.time_counter0;
-  long long work = 0;
+  long long work_done = 0;
   for (long long s = 0; s < p.nsteps; ++s) {
     if (p.cfg.atmoflux_flag == 2) {
       if (time > time_input(tc)) tc = tc + 1;
       if (tc > p.flen) tc = p.flen;
     }
     const bool out_step = (n_time_out == p.cfg.i_time_out) || (step + 1 == 1);
+    if (out_step) n_time_out = 0; else n_time_out = n_time_out + 1;
+    const bool next_out = (n_time_out == p.cfg.i_time_out);
     if (!c.status) {
       c.step = step;
-      work += c.Na;
-      column_step(c, x, col, time, tc, out_step);
+      work_done += c.Na;
+      c.ps = cur ? D_PSI_S2 : SAMSIM_A_PSI_S; c.pl = cur ? D_PSI_L2 : SAMSIM_A_PSI_L; c.pg = cur ? D_PSI_G2 : SAMSIM_A_PSI_G;
+      c.nps = cur ? SAMSIM_A_PSI_S : D_PSI_S2; c.npl = cur ? SAMSIM_A_PSI_L : D_PSI_L2; c.npg = cur ? SAMSIM_A_PSI_G : D_PSI_G2;
+      column_step(c, x, col, time, tc, out_step, next_out);
     }
-    if (out_step) n_time_out = 0; else n_time_out = n_time_out + 1;
+    cur ^= 1;
     time = time + p.cfg.dt;
     step = step + 1;
   }
 
-  p.n_active[col] = c.Na;
-  p.status[col] = c.status;
-  p.err_layer[col] = c.err_layer;
-  p.err_step[col] = c.err_step;
-  p.work[col] += work;
+  n_active[col] = c.Na;
+  flags[col] = c.flags;
+  status[col] = c.status;
+  err_layer[col] = c.err_layer;
+  err_step[col] = c.err_step;
+  work[col] += work_done;
 #define SSTORE(field, idx) sc[(size_t)(idx) * nc] = c.field
   SSTORE(m_snow, SAMSIM_S_M_SNOW); SSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SSTORE(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SSTORE(thick_snow, SAMSIM_S_THICK_SNOW); SSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SSTORE(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
@@ -1577,10 +1941,12 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
 
 }  // namespace
 
-// d_params: device copy of the parameter block; ncol: number of columns it describes
-extern "C" hipError_t samsim_launch_step(const DevParams *d_params, long long ncol, hipStream_t stream) {
+// d_params: device copy of the parameter block `hp` (host copy, used here for the direct pointer arguments)
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, hipStream_t stream) {
   const int block = SAMSIM_BLOCK;
-  const long long grid = (ncol + block - 1) / block;
-  hipLaunchKernelGGL(samsim_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params);
+  const long long grid = (hp->ncol + block - 1) / block;
+  hipLaunchKernelGGL(samsim_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
+                     hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
+                     hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active);
   return hipGetLastError();
 }

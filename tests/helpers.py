@@ -44,12 +44,14 @@ def assert_state_close(got: State, want: State, rtol=RTOL, arrays=None, scalars=
     """column-by-column comparison of two SoA states over the ACTIVE layers"""
     assert got.ncol == want.ncol and got.nlayer == want.nlayer
     assert np.array_equal(got.n_active, want.n_active), f"{what}: N_active differs"
-    arrays = arrays or ["H_abs", "S_abs", "m", "thick", "T", "phi", "psi_s", "psi_l", "S_bu", "S_br"]
+    # S_br and ray are step-internal hand-over arrays of the HIP path (not maintained at step boundaries); they are
+    # compared where the reference reads them: ray in the output snapshots
+    arrays = arrays or ["H_abs", "S_abs", "m", "thick", "T", "phi", "psi_s", "psi_l", "psi_g", "S_bu"]
     scalars = scalars if scalars is not None else [s for s in SCALARS if s not in DEAD_BETWEEN_OUTPUTS]
     k = np.arange(got.nlayer)[:, None] < want.n_active[None, :]
     for n in arrays:
         a, b = got.arr(n), want.arr(n)
-        floor = {"H_abs": 1e-3, "phi": 1e-9, "psi_s": 1e-9}.get(n, 1e-9)
+        floor = {"H_abs": 1e-3, "psi_g": 1e-6}.get(n, 1e-9)
         e = rel_err(a[k], b[k], floor)
         assert e <= rtol, f"{what}: array {n} rel err {e:.3e} > {rtol}"
     for n in scalars:
