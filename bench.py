@@ -164,6 +164,15 @@ def main():
         bytes_per_colstep = 16.0 * (4 * nlayer + 24)   # read + write once of the prognostic state
         mean_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_colstep * ncol * args.substeps / (mean_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE
+        # in separate passes, gfx950 correction applied: profiles/r1_hbm_counter_calibration.txt); None if this
+        # configuration has not been profiled
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(f"{args.workload}:{ncol}:{nlayer}:{args.substeps}")
+        except OSError:
+            pass
         out = {
             "metric": "column-timesteps/sec", "value": value, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall_max / args.steps,
@@ -175,7 +184,7 @@ def main():
             "layer_cell_updates_per_s": cells / wall_max,
             "failed_columns": int(fails),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "samsim_step_kernel", "mean_launch_ms": mean_ms,
                          "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps},
         }

@@ -123,14 +123,8 @@ __device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T
   double T = H / c_l, phi = phi_out;
   int rc = 0;
   if (S_br_clamped(s, T, S_bu) > S_bu && S_bu > 0.001) {
-    double T_fr = -1.0, T_0, f, ddT_f, sb;
-    // freezing temperature; tolerance 0.0001 is a float32 literal (:87)
-    while (fabs(S_br_poly(s, T_fr) / S_bu - 1.0) > (double)0.0001f) {
-      T_0 = T_fr;
-      f = S_br_poly(s, T_0) - S_bu;
-      ddT_f = ddT_S_br(s, T_0);
-      T_fr = T_0 - f / ddT_f;
-    }
+    double T_fr = 0.0, T_0, f, ddT_f, sb;
+    bool have_T_fr = false;
     T_0 = T_in;
     sb = S_br_poly(s, T_0);
     f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
@@ -139,7 +133,19 @@ __device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T
     int i = 0;
     while (fabs(f) > 1.0) {
       T_0 = T;
-      if (T_0 > 0.0 || T_0 < -200.0) T_0 = T_fr;
+      if (T_0 > 0.0 || T_0 < -200.0) {
+        // The reference computes the freezing temperature T_fr up front (mo_thermo_functions.f90:85-92) and only reads it
+        // here.  It has no other effect, so it is evaluated on first use: same value, no Newton loop in the common case.
+        if (!have_T_fr) {
+          T_fr = -1.0;
+          while (fabs(S_br_poly(s, T_fr) / S_bu - 1.0) > (double)0.0001f) {  // tolerance is a float32 literal (:87)
+            const double t0 = T_fr;
+            T_fr = t0 - (S_br_poly(s, t0) - S_bu) / ddT_S_br(s, t0);
+          }
+          have_T_fr = true;
+        }
+        T_0 = T_fr;
+      }
       sb = S_br_poly(s, T_0);
       f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.0000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
       ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
