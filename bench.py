@@ -8,8 +8,8 @@ One bench "step" = ONE launch of the hot path that advances every column `--subs
 (a launch is one pass of the time-loop body over the whole resident ensemble, repeated substeps times inside
 the kernel; columns never communicate).  Workload (config.workload): SURVEY.md section 8(d) cfg3 -- testcase 4 /
 SHEBA physics and forcing tables (boundflux 2, gravity drainage, flushing, flooding, snow), `--ncol` columns per
-GPU started from a spun-up single-column state (oracle checkpoint at day 200, committed fixture) with the
-per-column T2m / precipitation perturbation of cfg3.  The state is resident in HBM before the timed region.
+GPU; the initial state tiles a 256-member perturbed ensemble that was spun up 200 days from open water (committed
+fixture, tools/make_ensemble_fixture.py), so the lanes of a wave hold genuinely different columns.  The state is resident in HBM before the timed region.
 Multi-GPU: columns are sharded by rank, no data-path collective exists (weak scaling: per-GPU columns fixed).
 
 The JSON line also carries
@@ -40,34 +40,49 @@ def load_checkpoint(name):
 
 
 def workload(args):
+    """returns cfg, member states (prognostic arrays, scalars, N_active), per-member perturbation, clock, forcing, name"""
     from samsim_amd import testcases as tcs
+    from samsim_amd.capi import State
     if args.workload == "sheba":
-        cfg, _ = tcs.testcase4(1)
-        st, clock = load_checkpoint("tc4_spunup_state.npz")
-        z = np.load(os.path.join(ROOT, "tests", "golden", "sheba_forcing.npz"))
-        forcing = (z["fl_sw"], z["fl_lw"], z["T2m"], z["precip"])
-        name = "SHEBA/testcase-4 physics+forcing (cfg3), spun-up day-200 state, per-column perturbed T2m/precip"
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"sheba_ensemble_{args.nlayer}.npz"))
+        cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
+        st = State(np.ascontiguousarray(z["lay"]), np.ascontiguousarray(z["scal"]), np.ascontiguousarray(z["n_active"]))
+        pert = (np.ascontiguousarray(z["dT2m"]), np.ascontiguousarray(z["precip_scale"]))
+        clock = dict(time=float(z["time"]), step=int(z["step"]), n_time_out=int(z["n_time_out"]),
+                     time_counter=int(z["time_counter"]), n_outputs=int(z["n_outputs"]))
+        f = np.load(os.path.join(ROOT, "tests", "golden", "sheba_forcing.npz"))
+        forcing = (f["fl_sw"], f["fl_lw"], f["T2m"], f["precip"])
+        name = (f"SHEBA/testcase-4 physics+forcing (cfg3), {st.ncol}-member perturbed-T2m/precip ensemble spun up 200 days "
+                "from open water (tools/make_ensemble_fixture.py), members tiled over the columns")
     else:
         cfg, _ = tcs.testcase1(1)
         st, clock = load_checkpoint("tc1_spunup_state.npz")
-        forcing = None
+        st = State(np.ascontiguousarray(st.lay[:4]), st.scal, st.n_active)
+        pert, forcing = None, None
         name = "testcase-1 physics (cfg2), spun-up state replicated to identical columns"
-    return cfg, st, clock, forcing, name
+    return cfg, st, pert, clock, forcing, name
 
 
-def upload_replicated(solver, st1, ncol, chunk=65536):
-    """column 0 of st1 repeated over all columns of the handle, uploaded in chunks"""
-    rep = st1.replicate(min(chunk, ncol))
+def tile(a, n, col0=0):
+    """member = global column id mod nmember, along the last axis"""
+    idx = (np.arange(col0, col0 + n) % a.shape[-1])
+    return np.ascontiguousarray(a[..., idx])
+
+
+def upload_tiled(solver, st, ncol, col0, chunk=65536):
+    """prognostic arrays + scalars of member (global column id mod nmember), uploaded in chunks"""
+    from samsim_amd.capi import State
     c0 = 0
     while c0 < ncol:
         n = min(chunk, ncol - c0)
-        solver.set_state(rep if n == rep.ncol else rep.window(0, n), c0)
+        solver.set_state(State(tile(st.lay, n, col0 + c0), tile(st.scal, n, col0 + c0),
+                               tile(st.n_active, n, col0 + c0).astype(np.int32)), c0)
         c0 += n
 
 
-def cpu_baseline(cfg, st1, clock, forcing, col0, target_s):
+def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
     """oracle (C port of the reference algorithm) on a bounded sample of the same workload"""
-    from samsim_amd import testcases as tcs
+    from samsim_amd.capi import State
     from tests.oracle_lib import oracle_solver
     # a one-GPU box grants a 16-core CPU share whatever the affinity mask says
     cores = min(16, len(os.sched_getaffinity(0)))
@@ -75,9 +90,8 @@ def cpu_baseline(cfg, st1, clock, forcing, col0, target_s):
     o = oracle_solver(cfg, ncol)
     o.set_threads(cores)
     if forcing is not None:
-        dT, ps = tcs.ensemble_perturbation(ncol, col0)
-        o.set_forcing(*forcing, dT, ps)
-    o.set_state(st1.replicate(ncol))
+        o.set_forcing(*forcing, tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
+    o.set_state(State(tile(st.lay, ncol, col0), tile(st.scal, ncol, col0), tile(st.n_active, ncol, col0).astype(np.int32)))
     o.set_clock(**clock)
     t = time.perf_counter()
     o.step(50)
@@ -86,7 +100,6 @@ def cpu_baseline(cfg, st1, clock, forcing, col0, target_s):
     t = time.perf_counter()
     o.step(nsteps)
     dt = time.perf_counter() - t
-    work0, _ = o.get_work()
     return {"value": ncol * nsteps / dt, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{ncol} columns x {nsteps} steps of the same workload on {cores} OpenMP threads ({dt:.1f} s)"}
 
@@ -99,6 +112,7 @@ def main():
     ap.add_argument("--ncol", type=int, default=1 << 20, help="columns per GPU")
     ap.add_argument("--substeps", type=int, default=20, help="model time steps per launch")
     ap.add_argument("--workload", choices=["sheba", "tc1"], default="sheba")
+    ap.add_argument("--nlayer", type=int, default=100, help="SHEBA geometry: 100 (reference) or 80 (headline variant)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,14 +131,13 @@ def main():
     import samsim_amd
     from samsim_amd import testcases as tcs
 
-    cfg, st1, clock, forcing, wname = workload(args)
+    cfg, st, pert, clock, forcing, wname = workload(args)
     ncol = args.ncol
     col0 = rank * ncol
     g = samsim_amd.hip_solver(cfg, ncol, device=local_rank)
     if forcing is not None:
-        dT, ps = tcs.ensemble_perturbation(ncol, col0)
-        g.set_forcing(*forcing, dT, ps)
-    upload_replicated(g, st1, ncol)
+        g.set_forcing(*forcing, tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
+    upload_tiled(g, st, ncol, col0)
     g.set_clock(**clock)
     g.set_output_window(0, 0)
 
@@ -177,7 +190,7 @@ def main():
             "metric": "column-timesteps/sec", "value": value, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; spun-up synthetic ensemble state"
+            "data": "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; synthetic spun-up ensemble (fixture)"
                     if args.workload == "sheba" else "synthetic: replicated spun-up testcase-1 state",
             "config": {"workload": wname, "ncol_per_gpu": ncol, "nlayer": nlayer, "timesteps_per_step": args.substeps,
                        "parallelism": f"columns sharded over {world} GPU(s), no collective"},
@@ -189,7 +202,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, st1, clock, forcing, col0, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, st, pert, clock, forcing, col0, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
