@@ -93,6 +93,47 @@ def testcase4(ncol: int = 1, nlayer: int = 100, n_top: int = 20, n_bottom: int =
     return c, st
 
 
+def config5(ncol: int = 1, nlayer: int = 500):
+    """SURVEY.md section 8(d) cfg5 (LDS-pressure / high-resolution configuration): testcase-4 flags (gravity drainage +
+    flushing + flooding all active), Nlayer = 20 + (nlayer-40) + 20, thick_0 = 0.004 m, dt = 2 s
+    (stability number k_s*dt/(rho_s*c_s*thick_0**2) = 0.15 < 0.5, cf. mo_grotz.f90:376), every layer active from the start:
+    a brine-saturated slab with a linear -8 .. -1.9 C profile and S_bu = 5 g/kg (in the manner of testcase 5,
+    mo_init.f90:1270-1273) under 0.7 m of snow, with the SHEBA tables started in the melt season (day 340).
+    Returns (cfg, state, clock)."""
+    c = default_config()
+    c.testcase = 4
+    c.nlayer, c.n_top, c.n_bottom = nlayer, 20, 20
+    c.atmoflux_flag, c.precip_flag, c.boundflux_flag = 2, 1, 2
+    c.snow_flush_flag, c.flush_heat_flag, c.snow_precip_flag = 1, 2, 1
+    c.T_bottom, c.S_bu_bottom = -1.0, 34.0
+    c.thick_0, c.time_out, c.dt = 0.004, 86400.0, 2.0
+    c.time_total = c.time_out * 30.0
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.n_active[:] = nlayer
+    # linear temperature profile -8 C (top) .. -1.9 C (bottom), S_bu = 5 g/kg, brine-saturated (no gas, no excess volume):
+    # H from the enthalpy relation getT inverts (mo_thermo_functions.f90:95), m from V_s + V_l = thick
+    k = (np.arange(nlayer) + 0.5) / nlayer
+    T = -8.0 + (8.0 - 1.9) * k
+    S_br = -18.7 * T - 0.519 * T ** 2 - 0.00535 * T ** 3      # sea-salt liquidus, mo_thermo_functions.f90:324-326
+    S_bu = 5.0
+    phi = 1.0 - S_bu / S_br
+    H = -LATENT_HEAT + LATENT_HEAT * S_bu / S_br + 2020.0 * T + 7.6973 * T * T / 2.0
+    m = c.thick_0 / (phi / 920.0 + (1.0 - phi) / RHO_L)
+    st.arr("thick")[:] = c.thick_0
+    st.arr("m")[:] = m[:, None]
+    st.arr("S_abs")[:] = (S_bu * m)[:, None]
+    st.arr("H_abs")[:] = (H * m)[:, None]
+    # 0.7 m of snow: heavier than the slab's buoyancy, so flooding fires as well as drainage and (melt season) flushing
+    st.sc("thick_snow")[:] = 0.7
+    st.sc("m_snow")[:] = 0.7 * RHO_SNOW
+    st.sc("H_abs_snow")[:] = -st.sc("m_snow") * LATENT_HEAT
+    st.sc("psi_s_snow")[:] = RHO_SNOW / 920.0
+    day = 340
+    clock = dict(time=day * 86400.0, step=int(day * 86400 / c.dt), n_time_out=0, time_counter=day * 8 + 1, n_outputs=day)
+    return c, st, clock
+
+
 def read_forcing(directory: str, length: int = LENGTH_INPUT):
     """sub_input (mo_functions.f90:304-327): list-directed read of the first `length` values of
     flux_sw/flux_lw/T2m/precip.txt.input; returns (fl_sw, fl_lw, T2m, precip)."""

@@ -280,3 +280,75 @@ def test_full_size_cfg3_million_columns_properties():
     o.set_clock(**clock)
     o.step(nsteps)
     assert_state_close(g.get_state(0, 64), o.get_state(), what="cfg3 columns 0..63")
+
+
+def _ensemble(nlayer, n):
+    """first n members of the spun-up perturbed SHEBA ensemble fixture (prognostic arrays only)"""
+    from samsim_amd.capi import State
+    z = golden(f"sheba_ensemble_{nlayer}.npz")
+    cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
+    st = State(np.ascontiguousarray(z["lay"][:, :, :n]), np.ascontiguousarray(z["scal"][:, :n]),
+               np.ascontiguousarray(z["n_active"][:n]))
+    clock = dict(time=float(z["time"]), step=int(z["step"]), n_time_out=int(z["n_time_out"]),
+                 time_counter=int(z["time_counter"]), n_outputs=int(z["n_outputs"]))
+    return cfg, st, clock, z["dT2m"][:n], z["precip_scale"][:n]
+
+
+@pytest.mark.parametrize("nlayer", [100, 80])
+def test_spun_up_ensemble_members(nlayer):
+    """the bench workload in small: genuinely different columns (1.4-1.6 m of ice, 9-16 cm of snow) restarted from their
+    prognostic arrays only (the carried diagnostics are rebuilt by the first sweep), Nlayer 100 and the 80-layer
+    headline geometry (20 + 40 + 20)"""
+    n = 64
+    cfg, st, clock, dT, ps = _ensemble(nlayer, n)
+    g = samsim_amd.hip_solver(cfg, n)
+    o = oracle_solver(cfg, n)
+    o.set_threads(NTHREADS)
+    for s in (g, o):
+        s.set_forcing(*sheba_forcing(), dT, ps)
+        s.set_state(st)
+        s.set_clock(**clock)
+    g.step(3000)
+    o.step(3000)
+    sg, so = check(g, o, f"ensemble Nlayer {nlayer}")
+    assert len(np.unique(so.arr("H_abs")[cfg.n_top + 5])) == n   # members really differ
+
+
+def test_cfg5_nlayer500_all_brine_processes():
+    """BASELINE cfg5 in small: Nlayer 500 (20 + 460 + 20), dt 2 s, every layer active, heavy snow (flooding), a
+    temperature gradient (gravity drainage), SHEBA forcing in the melt season"""
+    n = 32
+    cfg, st, clock = tcs.config5(n, nlayer=500)
+    g, o = pair(cfg, n, st, clock, forcing=sheba_forcing())
+    g.step(1500)
+    o.step(1500)
+    sg, so = check(g, o, "cfg5 Nlayer 500")
+    assert so.sc("grav_drain").min() > 0.0 and so.arr("thick")[0].min() > cfg.thick_0   # drainage and flooding fired
+
+
+def test_full_size_cfg5_quarter_million_columns():
+    """BASELINE cfg5 size: 262 144 columns x 500 layers (20 GB of state).  Periodic perturbation (period 1024): column c
+    and c + 1024 must agree bitwise; no STOP code; columns 0..15 against the oracle."""
+    ncol, period, nsteps = 262144, 1024, 30
+    cfg, st1, clock = tcs.config5(1, nlayer=500)
+    dT, ps = tcs.ensemble_perturbation(period)
+    dT, ps = np.tile(dT, ncol // period), np.tile(ps, ncol // period)
+    g = samsim_amd.hip_solver(cfg, ncol)
+    g.set_forcing(*sheba_forcing(), dT, ps)
+    rep = st1.replicate(4096)
+    for c0 in range(0, ncol, 4096):
+        g.set_state(rep, c0)
+    g.set_clock(**clock)
+    g.step(nsteps)
+    assert not g.get_status()[0].any()
+    first = g.get_state(0, period, narr=4)
+    for c0 in (period, 100 * period, ncol - period):
+        other = g.get_state(c0, period, narr=4)
+        assert np.array_equal(other.lay, first.lay)
+    o = oracle_solver(cfg, 16)
+    o.set_threads(NTHREADS)
+    o.set_forcing(*sheba_forcing(), dT[:16], ps[:16])
+    o.set_state(st1.replicate(16))
+    o.set_clock(**clock)
+    o.step(nsteps)
+    assert_state_close(g.get_state(0, 16), o.get_state(), what="cfg5 columns 0..15")
