@@ -60,7 +60,8 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 };
 
 struct Col {
-  double *lay;  // already offset by the column index
+  double *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
+  unsigned col; // this lane's column: 32-bit, so that an access is <scalar row base> + <one 32-bit lane offset>
   size_t ncol;
   int N;
   int Na;       // N_active
@@ -86,8 +87,11 @@ struct Col {
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
 };
 
+// Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
+// bottom-up loops that run from the wave maximum of N_active); the lane only adds its 32-bit column offset, which lets
+// the compiler use scalar-base addressing (global_load ... v_off, s[base]) instead of a 64-bit VGPR address per array.
 #ifndef LAY
-#define LAY(a, k) c.lay[((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol]
+#define LAY(a, k) (c.lay + ((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 #endif
 #define STOPC(code, layer)            \
   do {                                \
@@ -98,6 +102,17 @@ struct Col {
     }                                 \
     return;                           \
   } while (0)
+
+// Wave-uniform maximum of a per-lane integer (64-wide butterfly + readfirstlane).  Layer loops run k over 1..wave_max
+// (or wave_max..1) with the body predicated on k <= N_active: k then lives in an SGPR and every row address
+// (array, k) is scalar arithmetic; a lane with fewer layers idles exactly as long as it would have waited for its wave.
+__device__ __forceinline__ int wave_max(int v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
@@ -511,7 +526,9 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
-  for (int k = Na; k >= 1; --k) {
+  const int kmax = wave_max(Na);
+  for (int k = kmax; k >= 1; --k) {
+    if (k > Na) continue;
     const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), thick = LAY(SAMSIM_A_THICK, k);
     double S_abs = LAY(SAMSIM_A_S_ABS, k);
     if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
@@ -880,7 +897,9 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
   Raw raw = load_raw(1), raw_n = raw;
   Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
-  for (int j = 1; j <= Na; ++j) {
+  const int jmax = wave_max(Na);
+  for (int j = 1; j <= jmax; ++j) {
+    if (j > Na) continue;
     if (j < Na) raw_n = load_raw(j + 1);
     // ---- A(j)
     const double V_ex = LAY(D_V_EX, j), thick = LAY(SAMSIM_A_THICK, j);
@@ -1165,7 +1184,9 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
   double kk_k = LAY(c.ps, Na) * k_s + LAY(c.pl, Na) * k_l;
-  for (int k = Na; k >= 1; --k) {
+  const int kmax = wave_max(Na);
+  for (int k = kmax; k >= 1; --k) {
+    if (k > Na) continue;
     double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
@@ -1869,7 +1890,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
   Col c;
-  c.lay = lay + col;
+  c.lay = lay;
+  c.col = (unsigned)col;
   c.ncol = (size_t)p.ncol;
   c.N = p.cfg.nlayer;
   c.Na = n_active[col];
