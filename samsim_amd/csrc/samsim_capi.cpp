@@ -47,8 +47,6 @@ struct samsim_handle {
   long long *err_step = nullptr, *work = nullptr;
   double *spec = nullptr;      // hand-over block of the up sweep, [DEV_NSPEC][ncol]
   int32_t *flags = nullptr;    // COLF_* per column
-  int buf = 0;                 // psi buffer that is current at the next step
-  int last_psi_buf = 0;        // psi buffer that was current during the last completed step
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
   int32_t flen = 0;
   double *out_lay = nullptr, *out_scal = nullptr;
@@ -102,6 +100,19 @@ __global__ void fill_i32(int32_t *dst, size_t n, int32_t v) {
   if (i < n) dst[i] = v;
 }
 
+// S_bu(k) = S_abs(k)/m(k) for the active layers: the kernel keeps the bulk salinity in registers only (every reader
+// derives it from S_abs and m), so the array is brought up to date when the host asks for the state
+__global__ void refresh_s_bu(double *lay, const int32_t *n_active, size_t ncol, int N, size_t col0, size_t w) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w) return;
+  const size_t c = col0 + i;
+  const int na = n_active[c];
+  for (int k = 0; k < na; ++k) {
+    const double m = lay[((size_t)SAMSIM_A_M * N + k) * ncol + c];
+    lay[((size_t)SAMSIM_A_S_BU * N + k) * ncol + c] = lay[((size_t)SAMSIM_A_S_ABS * N + k) * ncol + c] / m;
+  }
+}
+
 hipError_t fill(double *dst, size_t n, double v, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(fill_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, v);
@@ -142,7 +153,7 @@ int launch(samsim_handle *h, long long nsteps) {
   p.cfg = h->cfg;
   p.lay = h->lay; p.scal = h->scal; p.n_active = h->n_active; p.status = h->status; p.err_layer = h->err_layer;
   p.err_step = h->err_step; p.work = h->work;
-  p.spec = h->spec; p.flags = h->flags; p.buf0 = h->buf;
+  p.spec = h->spec; p.flags = h->flags;
   p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
   p.ncol = h->ncol;
   p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
@@ -153,8 +164,6 @@ int launch(samsim_handle *h, long long nsteps) {
   HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
   HIPCHK(samsim_launch_step(&h->d_params[s], &p, h->stream));
   HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
-  h->last_psi_buf = (int)((h->buf + nsteps - 1) & 1);
-  h->buf = (int)((h->buf + nsteps) & 1);
   advance_clock(h, nsteps);
   return SAMSIM_OK;
 }
@@ -231,7 +240,6 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_T * N * nc, N * nc, cfg->T_bottom, h->stream), "fill T");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_S_BU * N * nc, N * nc, cfg->S_bu_bottom, h->stream), "fill S_bu");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_PSI_L * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
-    ok = ok && hip_ok(fill(h->lay + (size_t)D_PSI_L2 * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
     ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream), "fill precip_scale");
     if (ok) {
       hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->n_active, nc, 1);
@@ -316,13 +324,6 @@ int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0) 
                      hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->n_active + col0, s->n_active, w * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(h->status + col0, 0, w * sizeof(int32_t)));
-  if (s->narr == SAMSIM_NARR) {
-    // the volume fractions are double-buffered on the device (samsim_kernels.hip): fill the second buffer too
-    const int pub[3] = {SAMSIM_A_PSI_S, SAMSIM_A_PSI_L, SAMSIM_A_PSI_G}, alt[3] = {D_PSI_S2, D_PSI_L2, D_PSI_G2};
-    for (int i = 0; i < 3; ++i)
-      HIPCHK(hipMemcpy2D(h->lay + (size_t)alt[i] * N * nc + col0, nc * sizeof(double), s->lay + (size_t)pub[i] * N * w,
-                         w * sizeof(double), w * sizeof(double), N, hipMemcpyHostToDevice));
-  }
   // the next step of these columns runs the full first sweep and treats RAY as the previous step's Rayleigh numbers
   hipLaunchKernelGGL(fill_i32, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, h->stream, h->flags + col0, w,
                      COLF_DIRTY | COLF_RESTART);
@@ -337,17 +338,14 @@ int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
   rc = check_soa(h, s, col0);
   if (rc) return rc;
   const size_t N = (size_t)s->nlayer, nc = (size_t)h->ncol, w = (size_t)s->ncol;
+  if (s->narr == SAMSIM_NARR && h->clk.step > 0) {
+    hipLaunchKernelGGL(refresh_s_bu, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, h->stream, h->lay, h->n_active, nc,
+                       (int)N, (size_t)col0, w);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy2D(s->lay, w * sizeof(double), h->lay + col0, nc * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
                      hipMemcpyDeviceToHost));
-  if (s->narr == SAMSIM_NARR && h->last_psi_buf == 1) {
-    // psi_s / psi_l / psi_g of the last completed step live in the second buffer (the first one already holds the
-    // fractions the up sweep prepared for the next step)
-    const int pub[3] = {SAMSIM_A_PSI_S, SAMSIM_A_PSI_L, SAMSIM_A_PSI_G}, alt[3] = {D_PSI_S2, D_PSI_L2, D_PSI_G2};
-    for (int i = 0; i < 3; ++i)
-      HIPCHK(hipMemcpy2D(s->lay + (size_t)pub[i] * N * w, w * sizeof(double), h->lay + (size_t)alt[i] * N * nc + col0,
-                         nc * sizeof(double), w * sizeof(double), N, hipMemcpyDeviceToHost));
-  }
   HIPCHK(hipMemcpy2D(s->scal, w * sizeof(double), h->scal + col0, nc * sizeof(double), w * sizeof(double), (size_t)SAMSIM_NSCAL,
                      hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(s->n_active, h->n_active + col0, w * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -13,9 +13,7 @@
 
 // device-internal layer arrays: the public ones (enum samsim_layer_array) followed by scratch
 enum dev_layer_array {
-  D_V_EX = SAMSIM_NARR,   // expelled brine volume V_ex(k) (mo_thermo_functions.f90:157); reused as R(k) in flush3
-  D_PSI_S2, D_PSI_L2, D_PSI_G2,  // second buffer of the volume fractions: the up sweep of step n reads the fractions of
-                                 // step n for the conductive stencil while it writes those of step n+1 (see samsim_kernels.hip)
+  D_V_EX = SAMSIM_NARR,   // scratch row: equivalent resistance R(k) of flush3 (mo_flush.f90:137-145)
   DEV_NARR
 };
 
@@ -42,7 +40,6 @@ struct DevParams {
   long long *work;
   double *spec;         // [DEV_NSPEC][ncol]
   int32_t *flags;       // [ncol] COLF_*
-  int32_t buf0;         // which psi buffer is current at the first step of this launch (0: SAMSIM_A_PSI_*, 1: D_PSI_*2)
   const double *f_sw, *f_lw, *f_T2m, *f_precip;
   int32_t flen;
   long long ncol;

@@ -65,8 +65,6 @@ struct Col {
   size_t ncol;
   int N;
   int Na;       // N_active
-  int ps, pl, pg;     // array ids of the CURRENT psi_s / psi_l / psi_g buffers (this step's Expulsion)
-  int nps, npl, npg;  // array ids of the buffers the up sweep fills for the next step
   int flags;          // COLF_*
   double *spec;       // [DEV_NSPEC] hand-over block, already offset by the column index
   int status, err_layer;
@@ -85,6 +83,7 @@ struct Col {
   double min_psi_s;  // MINVAL(psi_s(1:N_active)) of this step's Expulsion
   double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
+  double psi_l_top;  // psi_l(1) of this step's Expulsion (the albedo reads it before the down sweep stores the psi arrays)
 };
 
 // Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
@@ -254,8 +253,8 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   double A = 0.0, G = 0.0;
   for (int k = 1; k <= Na; ++k) {
     double th = LAY(SAMSIM_A_THICK, k);
-    A += LAY(c.ps, k) * th;
-    G += LAY(c.pg, k) * th;
+    A += LAY(SAMSIM_A_PSI_S, k) * th;
+    G += LAY(SAMSIM_A_PSI_G, k) * th;
   }
   double buoy = A * (rho_l - rho_s) + G * rho_l;
   double freeboard;
@@ -269,7 +268,7 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
       ++k;
       mk = LAY(SAMSIM_A_M, k);
       thk = LAY(SAMSIM_A_THICK, k);
-      double a = LAY(c.ps, k) * thk, g = LAY(c.pg, k) * thk;
+      double a = LAY(SAMSIM_A_PSI_S, k) * thk, g = LAY(SAMSIM_A_PSI_G, k) * thk;
       // buoyancy of the layers below k, mass of layers 1..k
       test2 = (k == Na) ? 0.0 : ((A - (Ap + a)) * (rho_l - rho_s) + (G - (Gp + g)) * rho_l);
       double test1 = (Mp + mk) + snowmass;
@@ -473,27 +472,36 @@ __device__ __forceinline__ void ray_scan_init(RayScan &r) {
   r.buoy_s = 0.0; r.min_psi_s = 1.0e300;
 }
 
-// Expulsion + permeability + Rayleigh number of layer k given its T, phi; writes psi_* into buffers (ps,pl,pg), V_ex, ray
+// Expulsion, mo_thermo_functions.f90:157-187: volume fractions and expelled brine volume of one layer
+struct Expelled { double psi_s, psi_l, psi_g, V_ex; };
+__device__ __forceinline__ Expelled expulsion(double phi, double thick, double m) {
+  Expelled e;
+  const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
+  e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
+  e.psi_s = V_s / thick;
+  e.psi_l = (V_l - e.V_ex) / thick;
+  e.psi_g = (thick - V_l - V_s + e.V_ex) / thick;
+  if (e.psi_l < 0.0) e.psi_l = 0.0;
+  if (e.psi_g < 0.0) e.psi_g = 0.0;
+  return e;
+}
+
+// Permeability + Rayleigh number of layer k from its T, phi (Expulsion evaluated in registers).  Only PHI (by the caller)
+// and ray are stored: the down sweep re-evaluates Expulsion from PHI, m and thick (same inputs, same operations) and
+// writes the psi arrays itself, which is cheaper than handing psi_s, psi_l, psi_g and V_ex over through HBM.
 __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bool do_ray, double T, double phi, double S_bu,
-                                         double m, double thick, int ps, int pl, int pg, RayScan &r) {
+                                         double m, double thick, RayScan &r) {
   const samsim_config &g = x.p->cfg;
   const double S_br = S_br_clamped(x.salt, T, S_bu);
-  const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
-  double V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
-  double psi_s = V_s / thick, psi_l = (V_l - V_ex) / thick, psi_g = (thick - V_l - V_s + V_ex) / thick;
-  if (psi_l < 0.0) psi_l = 0.0;
-  if (psi_g < 0.0) psi_g = 0.0;
-  r.min_psi_s = dmin(r.min_psi_s, psi_s);
-  r.buoy_s += psi_s * thick;
-  LAY(ps, k) = psi_s;
-  LAY(pl, k) = psi_l;
-  LAY(pg, k) = psi_g;
-  LAY(D_V_EX, k) = V_ex;
+  const Expelled e = expulsion(phi, thick, m);
+  r.min_psi_s = dmin(r.min_psi_s, e.psi_s);
+  r.buoy_s += e.psi_s * thick;
+  if (k == 1) c.psi_l_top = e.psi_l;
   if (do_ray) {
-    const double perm = x.p17 * pow_3p1(1000.0 * fabs(psi_l));  // mo_grav_drain.f90:105
+    const double perm = x.p17 * pow_3p1(1000.0 * fabs(e.psi_l));  // mo_grav_drain.f90:105
     if (k == Na) {
       r.S_br_bot = S_br;
-      r.bot = thick * psi_s / psi_s_min;
+      r.bot = thick * e.psi_s / psi_s_min;
       r.perm_bot = perm;
       r.botterm = r.bot / perm;
     } else {
@@ -540,10 +548,10 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     int rr = getT(s, H, S_bu, T_test, T, phi);
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
-    // phi is not stored: the second sweep rewrites it before anything reads it.  S_bu / S_br are not stored either:
-    // their only readers recompute them from T, S_abs, m (see sweep_expulsion_transfer, sweep_down_fused).
+    // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
     LAY(SAMSIM_A_T, k) = T;
-    s1_layer(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, c.ps, c.pl, c.pg, r);
+    LAY(SAMSIM_A_PHI, k) = phi;
+    s1_layer(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
   }
   c.min_psi_s = r.min_psi_s;
   c.buoy_s = r.buoy_s;
@@ -569,7 +577,8 @@ __device__ void prologue_top_layer(Col &c, const Ctx &x) {
   double T, phi = 0.0;
   const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
   LAY(SAMSIM_A_T, 1) = T;
-  s1_layer(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, c.ps, c.pl, c.pg, r);
+  LAY(SAMSIM_A_PHI, 1) = phi;
+  s1_layer(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, r);
   c.min_psi_s = r.min_psi_s;
   c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, 1);
@@ -586,23 +595,23 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   double buoy_g = 0.0;
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
   for (int k = 1; k <= Na; ++k) {
-    const double V_ex = LAY(D_V_EX, k);
     double m = LAY(SAMSIM_A_M, k);
+    const double thick = LAY(SAMSIM_A_THICK, k);
+    // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
+    const Expelled ex = expulsion(LAY(SAMSIM_A_PHI, k), thick, m);
+    const double V_ex = ex.V_ex;
+    double psi_g = ex.psi_g;
     double flm_next;
-    double psi_g = LAY(c.pg, k);
-    if (k == 1) {
-      flm_next = -V_ex * rho_l;
-      if (psi_g > 0.0) buoy_g += psi_g * LAY(SAMSIM_A_THICK, k);
-    } else if (psi_g < (double)0.001f) {
-      flm_next = -V_ex * rho_l + flm_k;
-      if (psi_g > 0.0) buoy_g += psi_g * LAY(SAMSIM_A_THICK, k);
+    if (k == 1 || psi_g < (double)0.001f) {
+      flm_next = (k == 1) ? -V_ex * rho_l : -V_ex * rho_l + flm_k;
     } else {
-      const double thick = LAY(SAMSIM_A_THICK, k);
       flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
       psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
-      LAY(c.pg, k) = psi_g;
-      buoy_g += psi_g * thick;
     }
+    if (psi_g > 0.0) buoy_g += psi_g * thick;
+    LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
+    LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
+    LAY(SAMSIM_A_PSI_G, k) = psi_g;
     const double m_in = m;
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
@@ -642,19 +651,19 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
 __device__ RARE void vital_signs(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
-  // the reference evaluates these at the top of the loop with the PREVIOUS step's volume fractions: those sit in the
-  // buffer that was current during the previous step (nps/npl); ps/pl already hold this step's layers >= 2
+  // (evaluated at the top of the loop with the PREVIOUS step's volume fractions, as in the reference: the psi arrays
+  // are rewritten by this step's down sweep only later)
   double sH = 0.0, sm = 0.0, sS = 0.0, resist = 0.0, sth = 0.0, sS1 = 0.0, sm1 = 0.0;
   for (int k = 1; k <= Na; ++k) {
     const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
     sH += H_abs; sm += m; sS += S_abs;
     if (k <= Na - 1) {
       const double thick = LAY(SAMSIM_A_THICK, k);
-      resist = resist + thick / (LAY(c.npl, k) * k_l + LAY(c.nps, k) * k_s);
+      resist = resist + thick / (LAY(SAMSIM_A_PSI_L, k) * k_l + LAY(SAMSIM_A_PSI_S, k) * k_s);
       sth += thick; sS1 += S_abs; sm1 += m;
     }
   }
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.nps, Na);
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
   c.energy_stored = c.H_abs_snow + sH - g.T_bottom * sm * c_l;
   c.freshwater = sm / rho_l;
   c.freshwater = c.freshwater * (1.0 - sS / sm / ref_salinity);
@@ -678,12 +687,12 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   double hp = 0.0, sth = 0.0;
   for (int k = 1; k <= Na - 1; ++k) {
     const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow_3p1(1000.0 * LAY(c.pl, k));
+    const double perm = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, k));
     hp = hp + thick / perm;
     sth += thick;
   }
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.ps, Na);
-  const double permN = x.p17 * pow_3p1(1000.0 * LAY(c.pl, Na));
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+  const double permN = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, Na));
   hp = hp + (thN * psN / psi_s_min) / permN;
   hp = (sth + thN * psN / psi_s_min) / hp;
   const double sall = sth + thN;
@@ -736,12 +745,12 @@ __device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
   const int Na = c.Na;
   if (g.harmonic_flag != 2) return;  // MINVAL variant does not depend on thick(1)
   double minp = 1.0e300, stp = 0.0, st = 0.0, height = 0.0;
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(c.ps, Na);
+  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
   const double bot = thN * psN / psi_s_min;
-  const double botterm = bot / (x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, Na))));
+  const double botterm = bot / (x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, Na))));
   for (int k = Na - 1; k >= 1; --k) {
     const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k)));
+    const double perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)));
     height = st + bot;
     minp = dmin(minp, perm);
     stp = stp + thick / perm;
@@ -793,9 +802,9 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
       S_br_j = LAY(SAMSIM_A_S_BR, j + 1);
       const double ray = LAY(SAMSIM_A_RAY, j);
       if (ray > ray_crit && S_br > S_br_j) {
-        const double psi_s = LAY(c.ps, j), m = LAY(SAMSIM_A_M, j);
+        const double psi_s = LAY(SAMSIM_A_PSI_S, j), m = LAY(SAMSIM_A_M, j);
         if (psi_s > 0.001 && r.S_abs / m > 0.1) {
-          const double psi_l = LAY(c.pl, j);
+          const double psi_l = LAY(SAMSIM_A_PSI_L, j);
           double flux = x_grav * (ray - ray_crit) * dt * thick;
           flux = dmin(flux, psi_l * rho_l * thick);
           r.S_abs = r.S_abs - flux * S_br;
@@ -902,8 +911,11 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
     if (j > Na) continue;
     if (j < Na) raw_n = load_raw(j + 1);
     // ---- A(j)
-    const double V_ex = LAY(D_V_EX, j), thick = LAY(SAMSIM_A_THICK, j);
-    double psi_g = LAY(c.pg, j), m = raw.m, S_abs = raw.S_abs, H_abs = LAY(SAMSIM_A_H_ABS, j);
+    const double thick = LAY(SAMSIM_A_THICK, j);
+    // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
+    const Expelled ex = expulsion(LAY(SAMSIM_A_PHI, j), thick, raw.m);
+    const double V_ex = ex.V_ex;
+    double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs, H_abs = LAY(SAMSIM_A_H_ABS, j);
     const double T = raw.T, S_br = raw.S_br;
     if (do_beer) {
       if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
@@ -916,9 +928,11 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
     } else {
       flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
       psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
-      LAY(c.pg, j) = psi_g;
     }
     if (psi_g > 0.0) buoy_g += psi_g * thick;
+    LAY(SAMSIM_A_PSI_S, j) = ex.psi_s;
+    LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
+    LAY(SAMSIM_A_PSI_G, j) = psi_g;
     m = m + flm_next - flm_j;
     if (flm_next < 0.0) {
       H_abs = H_abs + flm_next * T * c_l;
@@ -949,9 +963,9 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
     if (j <= Na - 1) {
       const double ray = LAY(SAMSIM_A_RAY, j);
       if (ray > ray_crit && S_br > raw_n.S_br) {
-        const double psi_s = LAY(c.ps, j);
+        const double psi_s = ex.psi_s;
         if (psi_s > 0.001 && S_abs / m > 0.1) {
-          const double psi_l = LAY(c.pl, j);
+          const double psi_l = ex.psi_l;
           double flux = x_grav * (ray - ray_crit) * dt * thick;
           flux = dmin(flux, psi_l * rho_l * thick);
           S_abs = S_abs - flux * S_br;
@@ -1011,8 +1025,7 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
 __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (g.boundflux_flag != 2) return 0.0;
-  const double psi_l1 = LAY(c.pl, 1);
-  c.albedo = func_albedo(c.thick_snow, c.T_snow, psi_l1, g.thick_min, g.albedo_flag);
+  c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, g.albedo_flag);
   if (time == time_input(tc)) {
     c.fl_sw = x.f_sw[tc - 1];
     c.fl_lw = x.f_lw[tc - 1];
@@ -1028,7 +1041,7 @@ __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
 __device__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
-  const double psi_s1 = LAY(c.ps, 1), psi_l1 = LAY(c.pl, 1), psi_g1 = LAY(c.pg, 1);
+  const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
   const double thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   const double k1 = psi_s1 * k_s + psi_l1 * k_l + psi_g1 * 0.0;
   if (g.boundflux_flag == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
@@ -1101,13 +1114,13 @@ __device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
   // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
-  double kk_k = LAY(c.ps, Na) * k_s + LAY(c.pl, Na) * k_l;
+  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
   for (int k = Na; k >= 1; --k) {
     double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(c.ps, k - 1) * k_s + LAY(c.pl, k - 1) * k_l;
+      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
       const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
@@ -1183,7 +1196,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  double kk_k = LAY(c.ps, Na) * k_s + LAY(c.pl, Na) * k_l;
+  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
@@ -1191,7 +1204,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(c.ps, k - 1) * k_s + LAY(c.pl, k - 1) * k_l;
+      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
       const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
@@ -1222,8 +1235,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
     LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_PHI, k) = phi;
-    LAY(SAMSIM_A_S_BU, k) = S_bu;
+    LAY(SAMSIM_A_PHI, k) = phi;   // = phi of the next step's first sweep for k >= 2: the hand-over to the next down sweep
     if (k > 1) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
       double S_bu_n = S_bu;
@@ -1231,7 +1243,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      s1_layer(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, c.nps, c.npl, c.npg, r);
+      s1_layer(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
     }
     flq_below = flq_k;
     T_k = T_u; th_k = th_u; kk_k = kk_u;
@@ -1281,7 +1293,7 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   double cnst = 0.0;
   for (int k = 1; k <= Na; ++k) cnst += LAY(SAMSIM_A_THICK, k);
   cnst = cnst * para_flush_horiz;
-  const double psi_l1 = LAY(c.pl, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
+  const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   c.melt_thick = dmin(c.melt_thick, psi_l1 * thick1);
   c.melt_thick = dmin(c.melt_thick, g.thick_0 / 3.0);
 
@@ -1293,10 +1305,10 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     const double thick = LAY(SAMSIM_A_THICK, k);
     double perm;
     if (g.snow_flush_flag == 1) {
-      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k) + 2.0 * LAY(c.pg, k)));
+      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k) + 2.0 * LAY(SAMSIM_A_PSI_G, k)));
       if (perm == 0.0) perm = 1.0;
     } else {
-      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(c.pl, k)));
+      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)));
     }
     LAY(SAMSIM_A_PERM, k) = perm;
     const double pm = dmax(perm, 0.00000000000000000000001);
@@ -1597,9 +1609,8 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
     for (int a = 0; a < SAMSIM_NARR; ++a) {
       if (a == SAMSIM_A_RAY) continue;  // captured before it was overwritten (see sweep_up_fused / column_step)
-      const int src = (a == SAMSIM_A_PSI_S) ? c.ps : (a == SAMSIM_A_PSI_L) ? c.pl : (a == SAMSIM_A_PSI_G) ? c.pg : a;
       for (int k = 1; k <= c.N; ++k) {
-        double v = LAY(src, k);
+        double v = LAY(a, k);
         if (a == SAMSIM_A_S_BU && k <= c.Na) v = LAY(SAMSIM_A_S_ABS, k) / LAY(SAMSIM_A_M, k);  // refresh of mo_grotz.f90:333-335
         x.out_lay[((size_t)a * c.N + (k - 1)) * on + oc] = v;
       }
@@ -1698,7 +1709,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
 
     // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
     {
-      const double psi_gN = LAY(c.pg, Na);
+      const double psi_gN = LAY(SAMSIM_A_PSI_G, Na);
       if (psi_gN > 0.0) {
         const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
         LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
@@ -1769,7 +1780,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   if (Na > 1 && g.flush_flag > 2 && g.boundflux_flag == 2) {
     c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
     c.melt_thick = 0.0;
-    const double psi_s1 = LAY(c.ps, 1);
+    const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
       c.freeboard = func_freeboard(c, x);
@@ -1777,7 +1788,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
       if (c.freeboard > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
-        sub_melt_thick(LAY(c.pl, 1), psi_s1, LAY(c.pg, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
                        c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
         if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
           // sub_melt_snow, mo_functions.f90:443-474
@@ -1847,8 +1858,8 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     if (Na < N && LAY(SAMSIM_A_THICK, kn) == 0.0) {  // scrub, :772-783
       LAY(SAMSIM_A_T, Na + 1) = g.T_bottom;
       LAY(SAMSIM_A_S_BU, Na + 1) = g.S_bu_bottom;
-      LAY(c.pl, Na + 1) = 1.0;
-      LAY(c.ps, Na + 1) = 0.0;
+      LAY(SAMSIM_A_PSI_L, Na + 1) = 1.0;
+      LAY(SAMSIM_A_PSI_S, Na + 1) = 0.0;
     }
   } else {
     if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
@@ -1898,10 +1909,9 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.status = status[col];
   c.err_layer = err_layer[col];
   c.err_step = err_step[col];
-  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0;
+  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
   c.spec = spec + col;
-  int cur = p.buf0;
   const size_t nc = (size_t)p.ncol;
   double *sc = scal + col;
 #define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
@@ -1936,11 +1946,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
-      c.ps = cur ? D_PSI_S2 : SAMSIM_A_PSI_S; c.pl = cur ? D_PSI_L2 : SAMSIM_A_PSI_L; c.pg = cur ? D_PSI_G2 : SAMSIM_A_PSI_G;
-      c.nps = cur ? SAMSIM_A_PSI_S : D_PSI_S2; c.npl = cur ? SAMSIM_A_PSI_L : D_PSI_L2; c.npg = cur ? SAMSIM_A_PSI_G : D_PSI_G2;
       column_step(c, x, col, time, tc, out_step, next_out);
     }
-    cur ^= 1;
     time = time + p.cfg.dt;
     step = step + 1;
   }
