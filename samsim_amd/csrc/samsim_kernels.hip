@@ -102,15 +102,21 @@ struct Col {
     return;                           \
   } while (0)
 
-// Wave-uniform maximum of a per-lane integer (64-wide butterfly + readfirstlane).  Layer loops run k over 1..wave_max
-// (or wave_max..1) with the body predicated on k <= N_active: k then lives in an SGPR and every row address
-// (array, k) is scalar arithmetic; a lane with fewer layers idles exactly as long as it would have waited for its wave.
+// Wave-uniform maximum of a per-lane integer over the lanes that are EXECUTING the call (the sweeps are called under
+// divergent conditions -- fused / unfused path, frozen columns -- so a shuffle butterfly would read stale registers of
+// inactive lanes).  Layer loops run k over 1..wave_max (or wave_max..1) with the body predicated on k <= N_active: k then
+// lives in an SGPR and every row address (array, k) is scalar arithmetic; a lane with fewer layers idles exactly as long
+// as it would have waited for its wave.
 __device__ __forceinline__ int wave_max(int v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
+  unsigned long long mask = __ballot(1);
+  int m = 0;
+  while (mask) {
+    const int lane = __ffsll((long long)mask) - 1;
+    const int val = __builtin_amdgcn_readlane(v, lane);
+    m = val > m ? val : m;
+    mask &= mask - 1;
   }
-  return __builtin_amdgcn_readfirstlane(v);
+  return m;
 }
 
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }

@@ -352,3 +352,36 @@ def test_full_size_cfg5_quarter_million_columns():
     o.set_clock(**clock)
     o.step(nsteps)
     assert_state_close(g.get_state(0, 16), o.get_state(), what="cfg5 columns 0..15")
+
+
+def test_sheba_melt_season_teacher_forced_windows():
+    """the melt season is chaotic in a free run (a 1e-15 difference is amplified to 1e-4 within a
+    few hundred steps once thin snow couples to a surface layer sitting at the psi_s = 0.4 melt threshold), so parity is
+    asserted teacher-forced: the HIP path is restarted from the oracle's state and must agree 1 000 steps later.
+    Every 3rd day of days 340..440 of the SHEBA run: melt onset, snow melt, flushing, melt ponds, top and bottom melt
+    regrids (N_active 100 -> below 45), first refreezing; 16 perturbed columns."""
+    st1, clock = load_checkpoint("tc4_melt_state.npz")   # oracle checkpoint at day 340
+    cfg, _ = tcs.testcase4(1)
+    n, window = 16, 1000
+    dT, ps = tcs.ensemble_perturbation(n)
+    o = oracle_solver(cfg, n)
+    o.set_threads(NTHREADS)
+    o.set_forcing(*sheba_forcing(), dT, ps)
+    o.set_state(st1.replicate(n))
+    o.set_clock(**clock)
+    g = samsim_amd.hip_solver(cfg, n)
+    g.set_forcing(*sheba_forcing(), dT, ps)
+    na_seen = set()
+    for day in range(340, 440):
+        if (day - 340) % 3 == 0:
+            k = o.get_clock()
+            g.set_state(o.get_state())
+            g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+            g.step(window)
+            o.step(window)
+            sg, so = check(g, o, f"teacher-forced day {day}", rtol=1e-6)
+            na_seen.update(int(v) for v in so.n_active)
+            o.step(8640 - window)
+        else:
+            o.step(8640)
+    assert min(na_seen) < 50 and max(na_seen) == 100, na_seen   # the regrids really happened inside the tested span
