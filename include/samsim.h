@@ -35,18 +35,19 @@ extern "C" {
 typedef struct samsim_config {
   int32_t struct_size;          /* = sizeof(samsim_config); ABI check                                */
   int32_t testcase;             /* selects the time-dependent forcing of mo_grotz.f90:503-565:
-                                   1 -> sub_test1 (T_top toggles), 4 -> sub_test4 (fl_q_bottom), 0 none */
+                                   1 sub_test1 (T_top toggles), 3 sub_test3 (snow fall), 4/7 sub_test4
+                                   (fl_q_bottom), 5 (S_abs reset at step 2), 0 none                   */
   int32_t nlayer, n_top, n_middle, n_bottom;          /* mo_data.f90:62-65                           */
-  int32_t atmoflux_flag;        /* 2: forcing tables (only value supported with boundflux_flag 2)    */
-  int32_t grav_flag;            /* 1 none, 2 Rayleigh-number gravity drainage                        */
+  int32_t atmoflux_flag;        /* 1 Notz climatology, 2 forcing tables, 3 fixed fl_sw / fl_rest     */
+  int32_t grav_flag;            /* 1 none, 2 Rayleigh-number gravity drainage, 3 simple              */
   int32_t prescribe_flag;       /* 1 (2 not supported)                                               */
   int32_t grav_heat_flag;       /* 1, 2                                                              */
   int32_t flush_heat_flag;      /* 1, 2                                                              */
   int32_t turb_flag;            /* 1, 2                                                              */
   int32_t salt_flag;            /* 1 sea salt, 2 NaCl                                                */
   int32_t boundflux_flag;       /* 1 cooling plate, 2 radiative balance (3 not supported)            */
-  int32_t flush_flag;           /* 1 none, 5 flush3 (4, 6 not supported)                             */
-  int32_t flood_flag;           /* 1 none, 2 flood (3 not supported)                                 */
+  int32_t flush_flag;           /* 1 none, 4 melt water removed, 5 flush3 (6 not supported)          */
+  int32_t flood_flag;           /* 1 none, 2 flood, 3 flood_simple                                   */
   int32_t bottom_flag;          /* 1, 2                                                              */
   int32_t debug_flag;           /* 1 (ignored)                                                       */
   int32_t precip_flag;          /* 0, 1                                                              */
@@ -77,6 +78,7 @@ enum samsim_scalar {
   SAMSIM_S_MELT_THICK_SNOW, SAMSIM_S_FL_Q_SNOW,
   SAMSIM_S_ENERGY_STORED, SAMSIM_S_FRESHWATER, SAMSIM_S_TOTAL_RESIST,     /* vital signs             */
   SAMSIM_S_THICKNESS, SAMSIM_S_BULK_SALIN,
+  SAMSIM_S_FL_REST,             /* bundled long-wave + turbulent flux (constant for atmoflux_flag 3) */
   SAMSIM_S_DT2M, SAMSIM_S_PRECIP_SCALE,                                   /* ensemble perturbation   */
   SAMSIM_NSCAL
 };

@@ -40,7 +40,7 @@ done
 # function-level harness against the unmodified reference modules (objects of the dump variant)
 B=$OUT/build_dump
 FOBJS=""
-for m in mo_parameters mo_data mo_functions mo_init mo_thermo_functions mo_mass mo_grav_drain mo_output mo_layer_dynamics mo_flush mo_snow; do FOBJS="$FOBJS $B/$m.o"; done
+for m in mo_parameters mo_data mo_functions mo_init mo_thermo_functions mo_mass mo_grav_drain mo_output mo_layer_dynamics mo_flush mo_snow mo_flood; do FOBJS="$FOBJS $B/$m.o"; done
 "$FC" $FFLAGS -module-dir "$B" "$HERE/ref_hook/func_harness.f90" $FOBJS -o "$OUT/samsim_ref_func"
 # run directory: forcing tables are symlinked (not copied) next to an output/ directory
 mkdir -p "$OUT/run/output"

@@ -261,6 +261,17 @@ double oracle_func_T_freeze(double S_bu, int salt_flag) {
   }
 }
 
+/* sub_notzflux, mo_functions.f90:270-289 (47.9, 53.1, 60., 300., 360 are default-REAL / integer literals) */
+static void sub_notzflux(double time, double *fl_sw, double *fl_rest) {
+  double day = time / 86400.0, a, b;
+  while (day > 360.0) day = day - 360.0;
+  a = (day - 164.0) / (double)47.9f;
+  b = (day - 206.0) / (double)53.1f;
+  *fl_sw = 314.0 * exp(-0.5 * (a * a));
+  *fl_rest = 118.0 * exp(-0.5 * (b * b)) + 179.0;
+  if (day < 60.0 || day > 300.0) *fl_sw = 0.0;
+}
+
 /* sub_turb_flux, mo_functions.f90:347-363 */
 static void sub_turb_flux(double T_bottom, double S_bu_bottom, double T, double *S_abs, double m, double dt) {
   double turb = Turb_A * exp(Turb_B * (-oracle_func_density(T_bottom, S_bu_bottom) + oracle_func_density(T, *S_abs / m))) * dt;
@@ -437,6 +448,50 @@ static void fl_grav_drain(column *c) {
   if (g->grav_heat_flag == 2) H_abs[Na] = H_abs[Na] + heat_loss - fl_up[Na] * c_l * g->T_bottom;
 
   for (k = 1; k <= N; k++) if (S_abs[k] < 0.0) STOP(1337, k);                        /* :197-200 */
+}
+
+/* fl_grav_drain_simple, mo_grav_drain.f90:218-278 (grav_flag 3): Rayleigh numbers as above, then every layer above the
+ * critical value loses 1 % of its salt (`0.99` is a float32 literal).  harmonic_perm is not initialised in the reference;
+ * the flang build reads zeros there. */
+static void fl_grav_drain_simple(column *c) {
+  const samsim_config *g = c->cfg;
+  int N = c->N, Na = c->N_active, k, kk;
+  double perm[SAMSIM_MAX_NLAYER + 2], harmonic_perm[SAMSIM_MAX_NLAYER + 2];
+  double temp, d_S_br, height, ray_mini = ray_crit, s;
+  double *S_br = c->S_br, *psi_l = c->psi_l, *psi_s = c->psi_s, *thick = c->thick, *S_abs = c->S_abs, *ray = c->ray;
+  const double p17 = pow(10.0, -17.0), p14 = pow(10.0, -14.0);
+  for (k = 1; k <= N; k++) { perm[k] = 0.0; harmonic_perm[k] = 0.0; }
+  perm[Na] = 9999999.0;
+  for (k = 1; k <= N - 1; k++) ray[k] = 0.0;
+  for (k = 1; k <= Na; k++) perm[k] = p17 * pow(1000.0 * fabs(psi_l[k]), 3.10);
+  if (g->harmonic_flag == 2) {
+    for (k = 1; k <= Na - 1; k++) {
+      temp = perm[k]; for (kk = k; kk <= Na - 1; kk++) if (perm[kk] < temp) temp = perm[kk];
+      if (temp < p14) {
+        harmonic_perm[k] = 0.0;
+      } else {
+        for (kk = k; kk <= Na - 1; kk++) harmonic_perm[k] = harmonic_perm[k] + thick[kk] / perm[kk];
+        harmonic_perm[k] = harmonic_perm[k] + (thick[Na] * psi_s[Na] / psi_s_min) / perm[Na];
+        s = 0.0; for (kk = k; kk <= Na - 1; kk++) s += thick[kk];
+        harmonic_perm[k] = (s + thick[Na] * psi_s[Na] / psi_s_min) / harmonic_perm[k];
+      }
+    }
+  }
+  for (k = 1; k <= Na - 1; k++) {
+    d_S_br = S_br[k] - S_br[Na];
+    s = 0.0; for (kk = k + 1; kk <= Na - 1; kk++) s += thick[kk];
+    height = s + thick[Na] * psi_s[Na] / psi_s_min;
+    if (g->harmonic_flag == 1) {
+      temp = perm[k]; for (kk = k; kk <= Na; kk++) if (perm[kk] < temp) temp = perm[kk];
+      ray[k] = grav_f * rho_l * bbeta * d_S_br * height * temp;
+    } else if (g->harmonic_flag == 2) {
+      ray[k] = grav_f * rho_l * bbeta * d_S_br * height * harmonic_perm[k];
+    }
+    ray[k] = ray[k] / (kappa_l * mu);
+    ray[k] = dmax(ray[k], 0.0);
+  }
+  for (k = Na - 1; k >= 1; k--) if (ray[k] > ray_mini) S_abs[k] = S_abs[k] * (double)0.99f;
+  c->grav_drain = 0.0;
 }
 
 /* ------------------------------------------------------------------ mo_snow.f90 */
@@ -694,6 +749,23 @@ static void flood(column *c) {
     c->m_snow = c->m_snow - shift / c->thick_snow * c->m_snow;
     c->thick_snow = c->thick_snow - shift;
   }
+}
+
+/* flood_simple, mo_flood.f90:167-210 (flood_flag 3) */
+static void flood_simple(column *c) {
+  const samsim_config *g = c->cfg;
+  double shift = c->freeboard - neg_free;
+  double flood_brine = -shift * c->psi_g_snow * rho_l;
+  double *S_abs = c->S_abs, *H_abs = c->H_abs, *m = c->m, *thick = c->thick;
+  thick[1] = thick[1] - shift;
+  S_abs[1] = S_abs[1] + g->S_bu_bottom * flood_brine;
+  H_abs[1] = H_abs[1] - shift / c->thick_snow * c->H_abs_snow;
+  H_abs[1] = H_abs[1] + g->T_bottom * c_l * flood_brine;
+  m[1] = m[1] - shift / c->thick_snow * c->m_snow;
+  m[1] = m[1] + flood_brine;
+  c->H_abs_snow = c->H_abs_snow + shift / c->thick_snow * c->H_abs_snow;
+  c->m_snow = c->m_snow + shift / c->thick_snow * c->m_snow;
+  c->thick_snow = c->thick_snow + shift;
 }
 
 /* ------------------------------------------------------------------ mo_flush.f90 */
@@ -1019,7 +1091,9 @@ static void sub_heat_fluxes(column *c) {
 
   if (g->boundflux_flag == 2) {                                                       /* :91-195 */
     c->albedo = oracle_func_albedo(c->thick_snow, c->T_snow, psi_l[1], thick_min, g->albedo_flag);
-    if (g->atmoflux_flag == 2) {
+    if (g->atmoflux_flag == 1) {
+      sub_notzflux(c->time + 86400.0 * 180.0, &c->fl_sw, &c->fl_rest);
+    } else if (g->atmoflux_flag == 2) {
       if (c->time == time_input(tc)) {
         c->fl_sw = c->fl_sw_input[tc - 1];
         c->fl_lw = c->fl_lw_input[tc - 1];
@@ -1113,6 +1187,33 @@ static void sub_heat_fluxes(column *c) {
   temp2 = s + c->H_abs_snow;
   if (fabs((temp1 - temp2) / dt) > 0.00001) STOP(431, 0);
 }
+
+/* function-level entry points for the secondary parametrisations (unit-level golden vectors) */
+void oracle_flood_simple(double freeboard, double *S_abs1, double *H_abs1, double *m1, double *thick1, double T_bottom,
+                         double S_bu_bottom, double psi_g_snow, double *H_abs_snow, double *m_snow, double *thick_snow) {
+  samsim_config g; column c; double S[2], H[2], m[2], th[2];
+  memset(&g, 0, sizeof g); memset(&c, 0, sizeof c);
+  g.T_bottom = T_bottom; g.S_bu_bottom = S_bu_bottom;
+  S[1] = *S_abs1; H[1] = *H_abs1; m[1] = *m1; th[1] = *thick1;
+  c.cfg = &g; c.S_abs = S; c.H_abs = H; c.m = m; c.thick = th;
+  c.freeboard = freeboard; c.psi_g_snow = psi_g_snow; c.H_abs_snow = *H_abs_snow; c.m_snow = *m_snow; c.thick_snow = *thick_snow;
+  flood_simple(&c);
+  *S_abs1 = S[1]; *H_abs1 = H[1]; *m1 = m[1]; *thick1 = th[1];
+  *H_abs_snow = c.H_abs_snow; *m_snow = c.m_snow; *thick_snow = c.thick_snow;
+}
+
+void oracle_fl_grav_drain_simple(int N, int N_active, int harmonic_flag, const double *psi_s, const double *psi_l,
+                                 const double *thick, const double *S_br, double *S_abs, double *ray) {
+  samsim_config g; column c;
+  memset(&g, 0, sizeof g); memset(&c, 0, sizeof c);
+  g.harmonic_flag = harmonic_flag;
+  c.cfg = &g; c.N = N; c.N_active = N_active;
+  c.psi_s = (double *)psi_s; c.psi_l = (double *)psi_l; c.thick = (double *)thick; c.S_br = (double *)S_br;
+  c.S_abs = S_abs; c.ray = ray;
+  fl_grav_drain_simple(&c);
+}
+
+void oracle_sub_notzflux(double time, double *fl_sw, double *fl_rest) { sub_notzflux(time, fl_sw, fl_rest); }
 
 /* ------------------------------------------------------------------ mo_grotz.f90:182-835 */
 
@@ -1225,7 +1326,7 @@ static void take_snapshot(column *c) {
   s[SAMSIM_S_FL_SW] = c->fl_sw; s[SAMSIM_S_FL_LW] = c->fl_lw; s[SAMSIM_S_MELT_THICK_SNOW] = c->melt_thick_snow;
   s[SAMSIM_S_FL_Q_SNOW] = c->fl_Q_snow;
   s[SAMSIM_S_ENERGY_STORED] = c->energy_stored; s[SAMSIM_S_FRESHWATER] = c->freshwater; s[SAMSIM_S_TOTAL_RESIST] = c->total_resist;
-  s[SAMSIM_S_THICKNESS] = c->thickness; s[SAMSIM_S_BULK_SALIN] = c->bulk_salin;
+  s[SAMSIM_S_THICKNESS] = c->thickness; s[SAMSIM_S_BULK_SALIN] = c->bulk_salin; s[SAMSIM_S_FL_REST] = c->fl_rest;
   s[SAMSIM_S_DT2M] = c->dT2m; s[SAMSIM_S_PRECIP_SCALE] = c->precip_scale;
   c->snap_valid = 1; c->snap_time = c->time; c->snap_step = c->step + 1; c->snap_N_active = c->N_active;
 }
@@ -1273,6 +1374,7 @@ static void step_part_b(column *c) {
     c->freeboard = freeboard_now(c);
     if (c->freeboard < 0.0) {
       if (g->flood_flag == 2) flood(c);
+      else if (g->flood_flag == 3 && c->freeboard < neg_free) flood_simple(c);
     }
   }
 
@@ -1281,10 +1383,13 @@ static void step_part_b(column *c) {
 
   /* gravity drainage :463-477 */
   if (g->grav_flag == 2 && Na > 1) { fl_grav_drain(c); CHECK(); }
+  else if (g->grav_flag == 3 && Na > 1) fl_grav_drain_simple(c);
 
   /* testcase specifics :503-565 */
   if (g->testcase == 1) sub_test1(c->time, &c->T_top);
+  else if (g->testcase == 3) { c->liquid_precip = 0.0; c->solid_precip = 0.15 / 86400.0 / 356.0; }  /* sub_test3, :172-187 */
   else if (g->testcase == 4 || g->testcase == 7) sub_test4(c->time, &c->fl_q_bottom);
+  else if (g->testcase == 5 && c->step + 1 == 2) { for (k = 1; k <= N; k++) S_abs[k] = 5.0 * m[k]; }   /* mo_grotz.f90:543-544 */
 
   /* heat fluxes :584 */
   sub_heat_fluxes(c); CHECK();
@@ -1335,7 +1440,14 @@ static void step_part_b(column *c) {
     double fv_old[SAMSIM_MAX_NLAYER + 2], fh_old[SAMSIM_MAX_NLAYER + 2];
     for (k = 1; k <= N; k++) { fv_old[k] = c->flush_v[k]; fh_old[k] = c->flush_h[k]; c->flush_v[k] = 0.0; c->flush_h[k] = 0.0; }
     if (Na > 1 && c->freeboard > 0.001) {
-      if (g->flush_flag == 5) {
+      if (g->flush_flag == 4) {                                                        /* mo_grotz.f90:704-713 */
+        if (c->melt_thick > 0.000000000001 && Na > 2) {
+          H_abs[1] = H_abs[1] - c->melt_thick * rho_l * c_l * c->T[1];
+          S_abs[1] = S_abs[1] * (1.0 - (c->melt_thick * rho_l) / m[1]);
+          thick[1] = thick[1] - c->melt_thick;
+          m[1] = m[1] - c->melt_thick * rho_l;
+        }
+      } else if (g->flush_flag == 5) {
         if (c->melt_thick > 0.000000000001 && Na > 2 && c->freeboard > 0.0) {
           c->freeboard = freeboard_now(c);
           flush3(c); CHECK();
@@ -1469,6 +1581,7 @@ static double *scal_slot(column *c, int idx) {
     case SAMSIM_S_ENERGY_STORED: return &c->energy_stored; case SAMSIM_S_FRESHWATER: return &c->freshwater;
     case SAMSIM_S_TOTAL_RESIST: return &c->total_resist; case SAMSIM_S_THICKNESS: return &c->thickness;
     case SAMSIM_S_BULK_SALIN: return &c->bulk_salin;
+    case SAMSIM_S_FL_REST: return &c->fl_rest;
     case SAMSIM_S_DT2M: return &c->dT2m; case SAMSIM_S_PRECIP_SCALE: return &c->precip_scale;
   }
   return NULL;

@@ -55,6 +55,12 @@ double oracle_func_k_snow(double m_snow, double thick_snow);
 double oracle_func_freeboard(int N_active, const double *psi_s, const double *psi_g, const double *m,
                              const double *thick, double m_snow, int freeboard_snow_flag);
 void   oracle_Expulsion(double phi, double thick, double m, double *psi_s, double *psi_l, double *psi_g, double *V_ex);
+/* 1-based arrays of length N+1 (index 0 unused), as above */
+void   oracle_flood_simple(double freeboard, double *S_abs1, double *H_abs1, double *m1, double *thick1, double T_bottom,
+                           double S_bu_bottom, double psi_g_snow, double *H_abs_snow, double *m_snow, double *thick_snow);
+void   oracle_fl_grav_drain_simple(int N, int N_active, int harmonic_flag, const double *psi_s, const double *psi_l,
+                                   const double *thick, const double *S_br, double *S_abs, double *ray);
+void   oracle_sub_notzflux(double time, double *fl_sw, double *fl_rest);
 
 #ifdef __cplusplus
 }

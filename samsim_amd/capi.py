@@ -60,7 +60,7 @@ SCALARS = [
     "phi_s", "T_top", "melt_thick", "T2m", "liquid_precip", "solid_precip", "fl_q_bottom",
     "grav_drain", "grav_salt", "grav_temp", "melt_out1", "melt_out2", "melt_out3", "melt_err",
     "freeboard", "T_freeze", "albedo", "fl_sw", "fl_lw", "melt_thick_snow", "fl_Q_snow",
-    "energy_stored", "freshwater", "total_resist", "thickness", "bulk_salin", "dT2m", "precip_scale",
+    "energy_stored", "freshwater", "total_resist", "thickness", "bulk_salin", "fl_rest", "dT2m", "precip_scale",
 ]
 S = {n: i for i, n in enumerate(SCALARS)}
 NSCAL = len(SCALARS)

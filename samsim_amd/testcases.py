@@ -1,5 +1,6 @@
 """Host-side mirror of the reference's per-testcase setup `init(testcase)` (mo_init.f90:73-2034) for the
-testcases in scope (1 and 4) plus the synthetic BASELINE configurations.
+testcases in scope (1, 3, 4, 5, 7: every shipped testcase that runs on boundflux_flag 1/2 without the tank and
+lab options) plus the synthetic BASELINE configurations.
 
 `init` in the reference fills the `mo_data` globals; here it returns the POD `Config` that crosses the C-ABI
 and the SoA initial `State`.  Defaults follow mo_init.f90:83-132, the common tail mo_init.f90:1981-2031.
@@ -16,6 +17,7 @@ RHO_L = 1028.0      # mo_parameters.f90:53
 C_L = 3400.0        # mo_parameters.f90:51
 RHO_SNOW = 330.0    # mo_parameters.f90:87
 LATENT_HEAT = 333500.0
+SIGMA = 5.6704 * float(np.float32(1e-8))   # mo_parameters.f90:59 (`1e-8` is a default-REAL literal)
 LENGTH_INPUT = 13148  # mo_grotz.f90:132
 
 
@@ -84,6 +86,68 @@ def testcase4(ncol: int = 1, nlayer: int = 100, n_top: int = 20, n_bottom: int =
     c.T_bottom, c.S_bu_bottom = -1.0, 34.0
     c.thick_0, c.time_out, c.dt = 0.01, 86400.0, 10.0
     c.time_total = c.time_out * 365.0 * 4.5
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[:] = st.arr("thick") * RHO_L
+    st.arr("S_abs")[:] = c.S_bu_bottom * st.arr("m")
+    st.arr("H_abs")[:] = 0.0
+    return c, st
+
+
+def testcase3(ncol: int = 1):
+    """mo_init.f90:1045-1080: Notz climatological fluxes (atmoflux 1) + constant snow fall (sub_test3), 20 layers of 3 cm."""
+    c = default_config()
+    c.testcase = 3
+    c.nlayer, c.n_top, c.n_bottom = 20, 5, 5
+    c.atmoflux_flag, c.precip_flag, c.boundflux_flag = 1, 0, 2
+    c.T_bottom, c.S_bu_bottom = -1.0, 34.0
+    c.thick_0, c.dt, c.time_out = 0.03, 60.0, 86400.0 * 3.5
+    c.time_total = c.time_out * 54.0 * 2.0 * 2.0
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.sc("fl_q_bottom")[:] = 8.0
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[:] = st.arr("thick") * RHO_L
+    st.arr("S_abs")[:] = c.S_bu_bottom * st.arr("m")
+    st.arr("H_abs")[:] = 0.0
+    return c, st
+
+
+def testcase5(ncol: int = 1):
+    """mo_init.f90:1210-1273: 1 m slab of fresh-ish ice (all 100 layers active) warmed by a fixed flux (atmoflux 3),
+    flushing only; the salinity is reset to 5 g/kg at step 2 (mo_grotz.f90:543-544)."""
+    c = default_config()
+    c.testcase = 5
+    c.nlayer, c.n_top, c.n_bottom = 100, 20, 10
+    c.boundflux_flag, c.atmoflux_flag, c.flush_heat_flag, c.flush_flag, c.grav_flag, c.flood_flag = 2, 3, 2, 5, 1, 1
+    c.T_bottom, c.S_bu_bottom = 0.0, 5.0
+    c.thick_0, c.dt, c.time_out = 0.01, 10.0, 3600.0 * 3.0
+    c.time_total = c.time_out * 24.0 * 10.0
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.n_active[:] = c.nlayer
+    st.sc("fl_sw")[:] = 0.0
+    st.sc("fl_rest")[:] = 290.0 ** 4 * SIGMA
+    st.sc("fl_q_bottom")[:] = 15.0
+    st.arr("thick")[:] = c.thick_0
+    st.arr("m")[:] = st.arr("thick") * RHO_L
+    st.arr("S_abs")[:] = st.arr("m") * c.S_bu_bottom
+    st.arr("H_abs")[:] = st.arr("m") * (-90.0) * C_L
+    return c, st
+
+
+def testcase7(ncol: int = 1):
+    """mo_init.f90:1360-1395: SHEBA forcing as testcase 4 with the simple parametrisations (albedo 1, grav 3, flush 4,
+    flood 3), 9 years."""
+    c = default_config()
+    c.testcase = 7
+    c.nlayer, c.n_top, c.n_bottom = 100, 20, 20
+    c.atmoflux_flag, c.precip_flag, c.boundflux_flag = 2, 1, 2
+    c.albedo_flag, c.grav_heat_flag, c.flush_heat_flag, c.flush_flag, c.grav_flag, c.flood_flag = 1, 2, 2, 4, 3, 3
+    c.T_bottom, c.S_bu_bottom = -1.0, 34.0
+    c.thick_0, c.time_out, c.dt = 0.01, 86400.0 / 2.0, 10.0
+    c.time_total = c.time_out * 365.0 * 9.0
     _finish(c)
     st = _blank_state(c, ncol)
     st.arr("thick")[0] = c.thick_0

@@ -14,6 +14,12 @@ Fixtures are DATA only -- inputs and expected outputs:
   tc1_spunup_state.npz /    step-boundary checkpoints (all SoA arrays + clock) produced with the CPU oracle, used as
   tc4_spunup_state.npz      start states for parity tests and bench.py
   func_golden.npz           function-level vectors from the reference modules (oracle/ref_hook/func_harness.f90)
+  tc3_ref_fullprec.npz      testcase 3 (Notz fluxes + constant snow fall), all 216 output points
+  tc5_ref_fullprec.npz      testcase 5 (fixed fluxes, flushing of a 1 m slab), scalars at all 240 output points, layers at every 6th
+  tc7_ref_fullprec.npz      testcase 7 (SHEBA with the simple parametrisations): scalars of the first 131 output points (the
+                            reference's fl_grav_drain_simple reads an uninitialised local, so its own trajectory depends on
+                            stack history), layers at selected ones, and teacher-forcing pairs through the first
+                            two years (growth, melt with flush_flag 4, refreeze)
 """
 import os
 import subprocess
@@ -82,7 +88,8 @@ def func_golden():
     raw = np.fromfile(os.path.join(RUN, "func_golden.bin"), dtype=np.uint8)
     pos, d = 0, {}
     names = {1: "getT_salt1", 2: "getT_salt2", 3: "liquidus_salt1", 4: "liquidus_salt2", 5: "density_ksnow",
-             6: "albedo", 7: "expulsion", 8: "freeboard"}
+             6: "albedo", 7: "expulsion", 8: "freeboard", 9: "flood_simple", 10: "grav_drain_simple",
+             11: "notzflux"}
     while pos < len(raw):
         tag, ncols, nrows, _ = (int(v) for v in raw[pos:pos + 16].view(np.int32))
         pos += 16
@@ -116,6 +123,30 @@ def main():
         d["tf_" + k] = v
     d["tf_days"] = np.array(pairs)
     np.savez_compressed(os.path.join(OUT, "tc4_ref_fullprec.npz"), **d)
+
+    # --- testcases 3 / 5 / 7 (secondary parametrisations)
+    def cached(tc, name, env=None):
+        path = os.path.join(RUN, name)
+        return read_dump(path) if os.path.exists(path) else run_ref(tc, name, env)
+    recs = cached(3, "tc3_dump.bin")
+    np.savez_compressed(os.path.join(OUT, "tc3_ref_fullprec.npz"), **pack(recs))
+    recs = cached(5, "tc5_dump.bin")
+    d = pack(recs[5::6])
+    d["index"] = np.arange(len(recs))[5::6]
+    for k, v in pack(recs, with_layers=False).items():
+        d["all_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "tc5_ref_fullprec.npz"), **d)
+    recs = cached(7, "tc7_dump.bin", {"SAMSIM_REF_MAXSTEPS": "6000000"})
+    sel = [0, 1, 2, 10, 40, 80, 120, 130]
+    d = pack([recs[i] for i in sel])
+    d["index"] = np.array(sel)
+    for k, v in pack(recs[:131], with_layers=False).items():
+        d["all_" + k] = v
+    pairs = [60, 125, 400, 700, 808, 812, 815, 822, 836, 844, 862, 882, 1000, 1300]
+    for k, v in pack([recs[i] for p in pairs for i in (p, p + 1)]).items():
+        d["tf_" + k] = v
+    d["tf_index"] = np.array(pairs)
+    np.savez_compressed(os.path.join(OUT, "tc7_ref_fullprec.npz"), **d)
 
     # --- spun-up step-boundary checkpoints from the oracle
     cfg, st = tcs.testcase1(1)

@@ -113,7 +113,7 @@ def test_tc4_sheba_first_100_days_bitwise(tc4_oracle):
 
 
 def _restore_midstep(o, ref, j, cfg):
-    """load the reference's mid-step state (taken inside `output`, mo_grotz.f90:363) into the oracle"""
+    """load the reference's mid-step state (taken inside `output`, mo_grotz.f90:363) into the oracle or the HIP solver"""
     from samsim_amd.capi import State, A, NARR
     N = cfg.nlayer
     st = State.empty(1, N, NARR)
@@ -122,7 +122,7 @@ def _restore_midstep(o, ref, j, cfg):
         st.arr(n)[:, 0] = ref["tf_a_" + n][j]
     for n in ["m_snow", "H_abs_snow", "S_abs_snow", "thick_snow", "psi_s_snow", "psi_l_snow", "psi_g_snow", "T_snow",
               "phi_s", "T_top", "melt_thick", "T2m", "liquid_precip", "solid_precip", "fl_q_bottom", "melt_err",
-              "freeboard", "T_freeze", "albedo", "fl_sw", "fl_lw", "melt_thick_snow", "fl_Q_snow"]:
+              "freeboard", "T_freeze", "albedo", "fl_sw", "fl_lw", "fl_rest", "melt_thick_snow", "fl_Q_snow"]:
         st.sc(n)[0] = ref["tf_s_" + n][j]
     st.sc("precip_scale")[0] = 1.0
     st.n_active[0] = ref["tf_N_active"][j]
@@ -154,6 +154,112 @@ def test_tc4_melt_season_teacher_forced():
             e = rel_err(out.sc(n)[0], ref["tf_s_" + n][j], 1e-9)
             assert e <= 1e-9, f"day {day}->{day + 1}: {n} rel err {e:.2e}"
         o.close()
+
+
+def _compare_output(out, ref, i, j, tag, layers=LAYERS + ["perm", "flush_v", "flush_h"], prefix="all_"):
+    """bit-for-bit: scalars of output i (`all_` rows), per-layer arrays of fixture row j (None: scalars only)"""
+    assert out.step == ref[prefix + "step"][i] and out.n_active[0] == ref[prefix + "N_active"][i], f"{tag}: step / N_active"
+    for n, rn in SCAL_MAP.items():
+        assert out.sc(n)[0] == ref[prefix + "s_" + rn][i], f"{tag}: scalar {n} {out.sc(n)[0]} vs {ref[prefix + 's_' + rn][i]}"
+    if j is None:
+        return
+    na = int(out.n_active[0])
+    for n in layers:
+        a, b = out.arr(n)[:na, 0], ref["a_" + n][j, :na]
+        if n == "ray":
+            a, b = a[:na - 1], b[:na - 1]
+        assert np.array_equal(a, b), f"{tag}: {n} differs, max {np.max(np.abs(a - b))}"
+
+
+def test_tc3_notz_fluxes_and_snowfall_bitwise():
+    """testcase 3 (atmoflux_flag 1 = sub_notzflux, precip_flag 0 with sub_test3's constant snow fall): all 216 output
+    points of the 756-day run against the flang-built reference, bit for bit"""
+    cfg, st = tcs.testcase3(1)
+    o = oracle_solver(cfg, 1)
+    o.set_state(st)
+    o.set_clock()
+    ref = golden("tc3_ref_fullprec.npz")
+    assert len(ref["step"]) == 216
+    for i in range(216):
+        _compare_output(o.run_to_output(), ref, i, i, f"tc3 output {i}", prefix="")
+    assert not o.get_status()[0].any()
+
+
+def test_tc5_fixed_flux_flushing_bitwise():
+    """testcase 5 (atmoflux_flag 3, all layers active from the start, salinity reset at step 2, flushing only): scalars at
+    all 240 output points, per-layer state at every 6th"""
+    cfg, st = tcs.testcase5(1)
+    o = oracle_solver(cfg, 1)
+    o.set_state(st)
+    o.set_clock()
+    ref = golden("tc5_ref_fullprec.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    assert len(ref["all_step"]) == 240
+    for i in range(240):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"tc5 output {i}")
+    assert not o.get_status()[0].any()
+
+
+def test_tc7_simple_parametrisations():
+    """testcase 7 (albedo 1, grav_flag 3, flush_flag 4, flood_flag 3 on SHEBA forcing).  The reference's
+    fl_grav_drain_simple accumulates into a local it never initialises (mo_grav_drain.f90:226,246-248), so the reference's
+    own trajectory depends on what earlier calls left on the stack (it changes when its debug output is switched on).  The
+    oracle starts that local from zero -- pinned by the function-level vectors below -- and agrees with the shipped
+    reference run bit for bit for the first 131 output points (65 days) and on every teacher-forced window of the fixture
+    (12-hour windows restarted from the reference's own state through growth, melt with flush_flag 4, and refreeze)."""
+    cfg, st = tcs.testcase7(1)
+    ref = golden("tc7_ref_fullprec.npz")
+    o = oracle_solver(cfg, 1)
+    o.set_forcing(*sheba_forcing())
+    o.set_state(st)
+    o.set_clock()
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    for i in range(131):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"tc7 output {i}")
+    for p, idx in enumerate(ref["tf_index"]):
+        _restore_midstep(o, ref, 2 * p, cfg)
+        o.step_part_b()
+        out = o.run_to_output()
+        j = 2 * p + 1
+        assert out.step == ref["tf_step"][j] and out.n_active[0] == ref["tf_N_active"][j], f"window {idx}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+            assert np.array_equal(out.arr(n)[:na, 0], ref["tf_a_" + n][j, :na]), f"window {idx}: {n}"
+        for n in ["m_snow", "thick_snow", "T_snow", "T_top", "freeboard", "thickness"]:
+            assert out.sc(n)[0] == ref["tf_s_" + n][j], f"window {idx}: {n}"
+    assert not o.get_status()[0].any()
+
+
+def test_function_level_vectors_secondary():
+    """flood_simple, fl_grav_drain_simple (local harmonic_perm starting from zero) and sub_notzflux against vectors from the
+    unmodified reference modules"""
+    import ctypes as C
+    lib = load_oracle()
+    g = golden("func_golden.npz")
+    d = C.c_double
+    P = C.POINTER(d)
+    lib.oracle_flood_simple.argtypes = [d, P, P, P, P, d, d, d, P, P, P]
+    for row in g["flood_simple"]:
+        fb, Sa, H, m, th, Tb, Sb, hs, ms, ts, pg = row[:11]
+        v = [d(x) for x in (Sa, H, m, th, hs, ms, ts)]
+        lib.oracle_flood_simple(fb, *[C.byref(x) for x in v[:4]], Tb, Sb, pg, *[C.byref(x) for x in v[4:]])
+        assert [x.value for x in v] == list(row[11:18])
+    lib.oracle_fl_grav_drain_simple.argtypes = [C.c_int] * 3 + [P] * 6
+    ndesal = 0
+    for row in g["grav_drain_simple"]:
+        a = [np.concatenate([[0.0], row[12 * i:12 * i + 12]]) for i in range(5)]    # 1-based psi_s psi_l thick S_abs S_br
+        na, flag = int(row[60]), int(row[61])
+        ray, Sa = np.zeros(13), a[3].copy()
+        lib.oracle_fl_grav_drain_simple(12, na, flag, a[0].ctypes.data_as(P), a[1].ctypes.data_as(P), a[2].ctypes.data_as(P),
+                                        a[4].ctypes.data_as(P), Sa.ctypes.data_as(P), ray.ctypes.data_as(P))
+        assert np.array_equal(ray[1:12], row[62:73]) and np.array_equal(Sa[1:], row[73:85]), (na, flag)
+        ndesal += int((row[73:85] != row[36:48]).sum())
+    assert ndesal >= 10
+    lib.oracle_sub_notzflux.argtypes = [d, P, P]
+    for t, sw, rest in g["notzflux"]:
+        a, b = d(), d()
+        lib.oracle_sub_notzflux(t, C.byref(a), C.byref(b))
+        assert (a.value, b.value) == (sw, rest)
 
 
 def test_function_level_vectors():
