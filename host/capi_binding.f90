@@ -17,8 +17,8 @@ MODULE mo_samsim_capi
                         S_GRAV_SALT = 17, S_GRAV_TEMP = 18, S_MELT_OUT1 = 19, S_MELT_OUT2 = 20, S_MELT_OUT3 = 21, &
                         S_MELT_ERR = 22, S_FREEBOARD = 23, S_T_FREEZE = 24, S_ALBEDO = 25, S_FL_SW = 26, S_FL_LW = 27, &
                         S_MELT_THICK_SNOW = 28, S_FL_Q_SNOW = 29, S_ENERGY_STORED = 30, S_FRESHWATER = 31, &
-                        S_TOTAL_RESIST = 32, S_THICKNESS = 33, S_BULK_SALIN = 34, S_DT2M = 35, S_PRECIP_SCALE = 36, &
-                        SAMSIM_NSCAL = 36
+                        S_TOTAL_RESIST = 32, S_THICKNESS = 33, S_BULK_SALIN = 34, S_FL_REST = 35, S_DT2M = 36, S_PRECIP_SCALE = 37, &
+                        SAMSIM_NSCAL = 37
 
   TYPE, BIND(C) :: samsim_config
      INTEGER(c_int32_t) :: struct_size, testcase, nlayer, n_top, n_middle, n_bottom

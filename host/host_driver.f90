@@ -16,6 +16,7 @@ MODULE mo_data
   IMPLICIT NONE
   INTEGER, PARAMETER :: wp = SELECTED_REAL_KIND(12, 307)   ! mo_parameters.f90:33
   REAL(wp), PARAMETER :: rho_l = 1028.0_wp, c_l = 3400._wp, k_s = 2.2_wp, rho_s = 920._wp, c_s = 2020.0_wp
+  REAL(wp), PARAMETER :: sigma = 5.6704_wp*1e-8   !< Stefan Boltzmann constant as written in mo_parameters.f90:59
 
   TYPE(samsim_config) :: cfg                 !< every flag / scalar that crosses the C-ABI
   INTEGER             :: testcase_id = 1
@@ -24,7 +25,7 @@ MODULE mo_data
   LOGICAL             :: perturb = .FALSE.   !< per-column T2m / precipitation perturbation (SURVEY.md 8d cfg3)
   INTEGER(c_int64_t)  :: max_steps = -1
   INTEGER             :: i_time, i_time_out
-  REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp
+  REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp
   INTEGER             :: N_bgc = 1
   ! host copies: SoA blocks, column fastest (= C layout [array][layer][column])
   REAL(c_double), ALLOCATABLE, TARGET    :: lay(:, :, :), scal(:, :)
@@ -52,8 +53,8 @@ CONTAINS
     cfg%k_snow_flush = 0.75_wp; cfg%max_flux_plate = 10000.0_wp
   END SUBROUTINE default_flags
 
-  !> per-testcase settings and initial state: testcase 1 (mo_init.f90:865-945) and 4 (mo_init.f90:1127-1207);
-  !! common tail mo_init.f90:1981-2031.  Namelist group &samsim_flags (unit nml_unit, if > 0) overrides the settings.
+  !> per-testcase settings and initial state: testcases 1 (mo_init.f90:865-945), 3 (:1045-1080), 4 (:1127-1207),
+  !! 5 (:1210-1273) and 7 (:1360-1395); common tail mo_init.f90:1981-2031.  Namelist group &samsim_flags (unit nml_unit, if > 0) overrides the settings.
   SUBROUTINE init(testcase, nml_unit)
     INTEGER, INTENT(in) :: testcase, nml_unit
     INTEGER :: Nlayer, N_top, N_bottom, ios
@@ -80,6 +81,27 @@ CONTAINS
        cfg%snow_flush_flag = 1; cfg%flush_heat_flag = 2; cfg%snow_precip_flag = 1
        cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
        cfg%thick_0 = 0.01_wp; cfg%time_out = 86400._wp; cfg%time_total = cfg%time_out*365._wp*4.5_wp; cfg%dt = 10._wp
+    ELSE IF (testcase == 3) THEN
+       cfg%nlayer = 20; cfg%n_top = 5; cfg%n_bottom = 5
+       cfg%atmoflux_flag = 1; cfg%precip_flag = 0; cfg%boundflux_flag = 2
+       fl_q_bottom = 8._wp
+       cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
+       cfg%thick_0 = 0.03_wp; cfg%time_out = 86400._wp*3.5_wp; cfg%time_total = cfg%time_out*54._wp*2._wp*2._wp
+       cfg%dt = 60._wp
+    ELSE IF (testcase == 5) THEN
+       cfg%nlayer = 100; cfg%n_top = 20; cfg%n_bottom = 10
+       cfg%boundflux_flag = 2; cfg%atmoflux_flag = 3; cfg%flush_heat_flag = 2; cfg%flush_flag = 5
+       cfg%grav_flag = 1; cfg%flood_flag = 1
+       fl_sw = 0._wp; fl_rest = 290._wp**4*sigma; fl_q_bottom = 15._wp
+       cfg%S_bu_bottom = 5._wp; cfg%T_bottom = 0._wp
+       cfg%thick_0 = 0.01_wp; cfg%time_out = 3600._wp*3._wp; cfg%time_total = cfg%time_out*24._wp*10._wp; cfg%dt = 10._wp
+    ELSE IF (testcase == 7) THEN
+       cfg%nlayer = 100; cfg%n_top = 20; cfg%n_bottom = 20
+       cfg%atmoflux_flag = 2; cfg%precip_flag = 1; cfg%boundflux_flag = 2
+       cfg%albedo_flag = 1; cfg%grav_heat_flag = 2; cfg%flush_heat_flag = 2
+       cfg%flush_flag = 4; cfg%grav_flag = 3; cfg%flood_flag = 3
+       cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
+       cfg%thick_0 = 0.01_wp; cfg%time_out = 86400._wp/2._wp; cfg%time_total = cfg%time_out*365._wp*9._wp; cfg%dt = 10._wp
     ELSE
        PRINT *, 'selected testcase does not exist'   ! mo_init.f90:1973-1976
        STOP 4321
@@ -128,15 +150,26 @@ CONTAINS
     scal(:, S_PRECIP_SCALE) = 1.0_wp
     scal(:, S_T_TOP) = T_top
     scal(:, S_FL_Q_BOTTOM) = fl_q_bottom
-    n_active = 1
-    ! the single initial water layer
-    lay(:, 1, A_THICK) = cfg%thick_0
-    lay(:, 1, A_M) = lay(:, 1, A_THICK)*rho_l
-    lay(:, 1, A_S_ABS) = cfg%S_bu_bottom*lay(:, 1, A_M)
-    IF (testcase == 1) THEN
-       lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom*c_l
+    scal(:, S_FL_SW) = fl_sw
+    scal(:, S_FL_REST) = fl_rest
+    IF (testcase == 5) THEN
+       ! a slab: every layer active, thick = thick_0, 5 g/kg, -90 c_l J/kg (mo_init.f90:1217,1270-1273)
+       n_active = cfg%nlayer
+       lay(:, :, A_THICK) = cfg%thick_0
+       lay(:, :, A_M) = lay(:, :, A_THICK)*rho_l
+       lay(:, :, A_S_ABS) = lay(:, :, A_M)*cfg%S_bu_bottom
+       lay(:, :, A_H_ABS) = lay(:, :, A_M)*(-90.0)*c_l
     ELSE
-       lay(:, 1, A_H_ABS) = 0._wp
+       n_active = 1
+       ! the single initial water layer
+       lay(:, 1, A_THICK) = cfg%thick_0
+       lay(:, 1, A_M) = lay(:, 1, A_THICK)*rho_l
+       lay(:, 1, A_S_ABS) = cfg%S_bu_bottom*lay(:, 1, A_M)
+       IF (testcase == 1) THEN
+          lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom*c_l
+       ELSE
+          lay(:, 1, A_H_ABS) = 0._wp
+       END IF
     END IF
     PRINT *, 'Initialization of testcase complete, testcase:', testcase
   END SUBROUTINE init

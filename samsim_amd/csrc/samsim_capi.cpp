@@ -74,11 +74,10 @@ int validate(const samsim_config &c) {
   if (!(c.dt > 0.0) || !(c.thick_0 > 0.0) || c.i_time_out < 0) return SAMSIM_ERR_ARG;
   auto in = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
   if (!in(c.boundflux_flag, {1, 2})) return SAMSIM_ERR_UNSUPPORTED;
-  if (c.boundflux_flag == 2 && c.atmoflux_flag != 2) return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.atmoflux_flag, {1, 2, 3})) return SAMSIM_ERR_UNSUPPORTED;
-  if (!in(c.grav_flag, {1, 2}) || c.prescribe_flag != 1 || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
+  if (!in(c.grav_flag, {1, 2, 3}) || c.prescribe_flag != 1 || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
-  if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 5}) || !in(c.flood_flag, {1, 2}))
+  if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 4, 5}) || !in(c.flood_flag, {1, 2, 3}))
     return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || c.tank_flag != 1)
     return SAMSIM_ERR_UNSUPPORTED;

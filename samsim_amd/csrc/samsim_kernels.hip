@@ -244,6 +244,7 @@ struct Ctx {
   // know they are global-memory pointers (global_load/global_store with scalar base) instead of generic flat ones.
   const double *f_sw, *f_lw, *f_T2m, *f_precip;
   double *out_lay, *out_scal;
+  double *scal;  // [SAMSIM_NSCAL][ncol] scalar block: slots that are not carried in registers (fl_rest) are read / written in place
   int32_t *out_n_active;
   long long out_col0, out_ncols;
   Salt salt;
@@ -534,7 +535,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
-  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
   double T_test = g.T_bottom;
   RayScan r;
   ray_scan_init(r);
@@ -570,7 +571,7 @@ __device__ void prologue_top_layer(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const size_t nc = c.ncol;
-  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
   RayScan r;
   r.minp = c.spec[SP_MINP * nc]; r.stp = c.spec[SP_STP * nc]; r.st = c.spec[SP_ST * nc];
   r.bot = c.spec[SP_BOT * nc]; r.botterm = c.spec[SP_BOTTERM * nc]; r.perm_bot = c.spec[SP_PERM_BOT * nc];
@@ -745,6 +746,27 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   LAY(SAMSIM_A_THICK, 1) = th1;
 }
 
+// ---------------------------------------------------------------- flood_simple, mo_flood.f90:167-210 (flood_flag 3)
+__device__ RARE void flood_simple(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const double shift = c.freeboard - neg_free;
+  const double flood_brine = -shift * c.psi_g_snow * rho_l;
+  double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
+  th1 = th1 - shift;
+  S1 = S1 + g.S_bu_bottom * flood_brine;
+  H1 = H1 - shift / c.thick_snow * c.H_abs_snow;
+  H1 = H1 + g.T_bottom * c_l * flood_brine;
+  m1 = m1 - shift / c.thick_snow * c.m_snow;
+  m1 = m1 + flood_brine;
+  c.H_abs_snow = c.H_abs_snow + shift / c.thick_snow * c.H_abs_snow;
+  c.m_snow = c.m_snow + shift / c.thick_snow * c.m_snow;
+  c.thick_snow = c.thick_snow + shift;
+  LAY(SAMSIM_A_S_ABS, 1) = S1;
+  LAY(SAMSIM_A_H_ABS, 1) = H1;
+  LAY(SAMSIM_A_M, 1) = m1;
+  LAY(SAMSIM_A_THICK, 1) = th1;
+}
+
 // recompute ray(1) after flood changed thick(1) (thick(1) enters only the k = 1 harmonic mean)
 __device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
@@ -864,6 +886,23 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
   c.grav_salt = c.grav_salt - sum_after;
   if (stop_layer) STOPC(21234, stop_layer);
   if (minS < 0.0) STOPC(1337, 0);
+}
+
+// fl_grav_drain_simple (mo_grav_drain.f90:218-278, grav_flag 3) with ray(k) from S1: every layer above the critical
+// Rayleigh number loses 1 % of its salt (`0.99` is a default-REAL literal); fused with the Beer-law pass like P3.
+__device__ RARE void sweep_grav_drain_simple(Col &c, bool do_beer, double beer0) {
+  const int Na = c.Na;
+  double temp2 = beer0, e = 0.0, th_prev = -1.0;
+  for (int k = 1; k <= Na; ++k) {
+    if (do_beer) {
+      const double thick = LAY(SAMSIM_A_THICK, k);
+      if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
+      if (k == Na) c.frad = temp2 - temp2 * e;
+      temp2 = temp2 * e;
+    }
+    if (k <= Na - 1 && LAY(SAMSIM_A_RAY, k) > ray_crit) LAY(SAMSIM_A_S_ABS, k) = LAY(SAMSIM_A_S_ABS, k) * (double)0.99f;
+  }
+  c.grav_drain = 0.0;
 }
 
 // Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
@@ -1032,13 +1071,24 @@ __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (g.boundflux_flag != 2) return 0.0;
   c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, g.albedo_flag);
-  if (time == time_input(tc)) {
-    c.fl_sw = x.f_sw[tc - 1];
-    c.fl_lw = x.f_lw[tc - 1];
-  } else {
-    const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-    c.fl_sw = (1.0 - temp) * x.f_sw[tc - 2] + temp * x.f_sw[tc - 1];
-    c.fl_lw = (1.0 - temp) * x.f_lw[tc - 2] + temp * x.f_lw[tc - 1];
+  if (g.atmoflux_flag == 2) {
+    if (time == time_input(tc)) {
+      c.fl_sw = x.f_sw[tc - 1];
+      c.fl_lw = x.f_lw[tc - 1];
+    } else {
+      const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
+      c.fl_sw = (1.0 - temp) * x.f_sw[tc - 2] + temp * x.f_sw[tc - 1];
+      c.fl_lw = (1.0 - temp) * x.f_lw[tc - 2] + temp * x.f_lw[tc - 1];
+    }
+  } else if (g.atmoflux_flag == 1) {
+    // sub_notzflux(time + 180 days), mo_functions.f90:270-289 (47.9, 53.1 are default-REAL literals); fl_rest lives in
+    // the scalar block (atmoflux_flag 3 leaves fl_sw and fl_rest as the caller set them)
+    double day = (time + 86400.0 * 180.0) / 86400.0;
+    while (day > 360.0) day = day - 360.0;
+    const double a = (day - 164.0) / (double)47.9f, b = (day - 206.0) / (double)53.1f;
+    c.fl_sw = 314.0 * exp(-0.5 * (a * a));
+    if (day < 60.0 || day > 300.0) c.fl_sw = 0.0;
+    x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col] = 118.0 * exp(-0.5 * (b * b)) + 179.0;
   }
   const double pen = (c.thick_snow < g.thick_min) ? penetr : 0.0;
   return pen * (1.0 - c.albedo) * c.fl_sw;
@@ -1058,7 +1108,7 @@ __device__ void surface_flux(Col &c, const Ctx &x) {
   }
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
-  const double fl_rest = c.fl_lw + 0.0 + 0.0;
+  const double fl_rest = (g.atmoflux_flag == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
   double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
@@ -1186,7 +1236,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
   const size_t nc = c.ncol;
   const double dt = g.dt, thick_min = g.thick_min;
   const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
-  const bool do_ray = (g.grav_flag == 2 && Na > 1);
+  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
   const bool keep_ray = next_is_output && col >= x.out_col0 && col < x.out_col0 + x.out_ncols;
   const double H_abs_snow_before = c.H_abs_snow;
   double sum_before = 0.0, sum_after = 0.0;
@@ -1635,6 +1685,8 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
+    OUT(SAMSIM_S_FL_REST, (g.atmoflux_flag == 2 && g.boundflux_flag == 2) ? c.fl_lw + 0.0 + 0.0
+                                                                        : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
     OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
 #undef OUT
     x.out_n_active[oc] = c.Na;
@@ -1642,6 +1694,20 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
   c.grav_drain = 0.0; c.grav_salt = 0.0; c.grav_temp = 0.0;
   c.melt_out1 = 0.0; c.melt_out2 = 0.0; c.melt_out3 = 0.0;
   (void)time;
+}
+
+// testcase specifics that only touch scalars, mo_grotz.f90:503-565
+__device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g, double time) {
+  if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
+    for (int n = 1; n <= 20; ++n) {
+      if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+    }
+  } else if (g.testcase == 3) {  // sub_test3, :172-187
+    c.liquid_precip = 0.0;
+    c.solid_precip = 0.15 / 86400.0 / 356.0;
+  } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
+    c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+  }
 }
 
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
@@ -1692,18 +1758,13 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   const bool coupling = (c.m_snow > 0.0 && c.thick_snow < g.thick_min);
   const bool flood_possible = (g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0 &&
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
-  const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible;
+  const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
+                     !(g.testcase == 5 && c.step + 1 == 2);
 
   if (fused) {
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
-    if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
-      for (int n = 1; n <= 20; ++n) {
-        if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
-      }
-    } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
-      c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
-    }
+    testcase_scalars(c, g, time);
     const double beer0 = radiation_header(c, x, time, tc);
     c.frad = 0.0;
     sweep_down_fused(c, x, do_beer, beer0);
@@ -1737,7 +1798,10 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
         c.freeboard = (buoy - c.m_snow) / rho_l;
         if (c.freeboard < 0.0 && g.flood_flag == 2) {
           flood(c, x);
-          if (g.grav_flag == 2) refresh_ray_top(c, x);
+          if (g.grav_flag >= 2) refresh_ray_top(c, x);
+        } else if (g.flood_flag == 3 && c.freeboard < neg_free) {
+          flood_simple(c, x);
+          if (g.grav_flag >= 2) refresh_ray_top(c, x);
         }
       }
     }
@@ -1750,14 +1814,8 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
       LAY(SAMSIM_A_S_ABS, Na) = S_abs;
     }
 
-    // testcase specifics, mo_grotz.f90:503-565
-    if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
-      for (int n = 1; n <= 20; ++n) {
-        if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
-      }
-    } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
-      c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
-    }
+    // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
+    testcase_scalars(c, g, time);
 
     // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
     const double beer0 = radiation_header(c, x, time, tc);
@@ -1765,8 +1823,13 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
     if (do_grav) {
       sweep_grav_drain(c, x, do_beer, beer0);
       if (c.status) return;
+    } else if (g.grav_flag == 3 && Na > 1) {
+      sweep_grav_drain_simple(c, do_beer, beer0);
     } else if (do_beer) {
       sweep_beer(c, beer0);
+    }
+    if (g.testcase == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
+      for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
     }
   }
 
@@ -1825,8 +1888,9 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   }
 
   // flushing, mo_grotz.f90:670-737
-  // freeboard (:670) is only read when flush3 can run (:715-716): flush_flag 5, N_active > 2 and melt water present
-  const bool flush_possible = (g.flush_flag == 5 && Na > 2 && c.melt_thick + c.melt_thick_snow > 0.000000000001);
+  // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
+  const bool flush_possible = ((g.flush_flag == 5 || g.flush_flag == 4) && Na > 2 &&
+                               c.melt_thick + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !fb_valid) c.freeboard = func_freeboard(c, x);
   c.melt_out1 = c.melt_out1 + c.melt_thick;
   c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
@@ -1843,10 +1907,18 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   }
   if (flush_possible && c.freeboard > 0.001) {
     if (c.melt_thick > 0.000000000001) {
-      if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation (:717)
-      flush3(c, x);
-      c.flags |= COLF_DIRTY;
-      if (c.status) return;
+      if (g.flush_flag == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
+        const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
+        LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - c.melt_thick * rho_l * c_l * T1;
+        LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (c.melt_thick * rho_l) / m1);
+        LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - c.melt_thick;
+        LAY(SAMSIM_A_M, 1) = m1 - c.melt_thick * rho_l;
+      } else {
+        if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation (:717)
+        flush3(c, x);
+        c.flags |= COLF_DIRTY;
+        if (c.status) return;
+      }
     }
   }
 
@@ -1901,6 +1973,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.p = pp;
   x.f_sw = f_sw; x.f_lw = f_lw; x.f_T2m = f_T2m; x.f_precip = f_precip;
   x.out_lay = out_lay; x.out_scal = out_scal; x.out_n_active = out_n_active;
+  x.scal = scal;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   if (p.cfg.salt_flag == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
@@ -1978,6 +2051,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SSTORE(energy_stored, SAMSIM_S_ENERGY_STORED); SSTORE(freshwater, SAMSIM_S_FRESHWATER); SSTORE(total_resist, SAMSIM_S_TOTAL_RESIST);
   SSTORE(thickness, SAMSIM_S_THICKNESS); SSTORE(bulk_salin, SAMSIM_S_BULK_SALIN);
 #undef SSTORE
+  // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112
+  if (p.cfg.atmoflux_flag == 2 && p.cfg.boundflux_flag == 2) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
 }
 
 }  // namespace

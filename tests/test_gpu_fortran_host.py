@@ -61,3 +61,33 @@ def test_fortran_host_namelist_overrides_and_sheba(tmp_path):
     # grav_heat_flag differs from the reference run, so only the first output point (before any drainage) is comparable
     assert np.abs(T[0] - np.round(ref["a_T"][0], 3)).max() <= 1.5e-3
     assert "grav_heat_flag          2" in (tmp_path / "output" / "dat_settings.dat").read_text()
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")
+def test_fortran_host_testcases_3_and_5(tmp_path):
+    """init(3) (Notz fluxes, constant snow fall) and init(5) (slab, fixed fl_sw / fl_rest) in the Fortran host: the printed
+    temperature and thickness profiles follow the reference's full-precision records of the same output points"""
+    d3 = tmp_path / "tc3"
+    d3.mkdir()
+    out = run_host(d3, "&samsim_run testcase=3, ncol=8, max_steps=250000 /\n")
+    assert "SAMSIM is finished" in out
+    ref = golden("tc3_ref_fullprec.npz")
+    T, th = load(d3, "T"), load(d3, "thick")
+    n = T.shape[0]
+    assert n == 50 and T.shape[1] == 20                      # outputs every 5040 steps + step 1
+    for i in range(n):
+        na = int(ref["N_active"][i])
+        assert np.abs(T[i, :na] - ref["a_T"][i, :na]).max() <= 1.5e-3, f"tc3 output {i}"
+        assert np.abs(th[i, :na] - ref["a_thick"][i, :na]).max() <= 1.5e-5, f"tc3 output {i}"
+    assert "atmoflux_flag           1" in (d3 / "output" / "dat_settings.dat").read_text()
+    d5 = tmp_path / "tc5"
+    d5.mkdir()
+    out = run_host(d5, "&samsim_run testcase=5, ncol=8, max_steps=40000 /\n")
+    ref = golden("tc5_ref_fullprec.npz")
+    T = load(d5, "T")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    assert T.shape == (38, 100)
+    for i, j in rows.items():
+        if i < T.shape[0]:
+            na = int(ref["all_N_active"][i])
+            assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc5 output {i}"

@@ -1,0 +1,169 @@
+"""Parity of the HIP path on the secondary parametrisations: testcases 3, 5 and 7 of the
+reference -- Notz climatological fluxes (atmoflux_flag 1), fixed fluxes (3), constant snow fall with precip_flag 0,
+fl_grav_drain_simple (grav_flag 3), melt-water removal (flush_flag 4), flood_simple (flood_flag 3), albedo_flag 1.
+Same bar as tests/test_gpu_parity.py: 1e-6 relative against the CPU oracle, integers exact; the oracle itself is
+pinned bit for bit against the flang-built reference on these testcases (tests/test_oracle_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import samsim_amd
+from samsim_amd import testcases as tcs
+from tests.helpers import RTOL, assert_state_close, golden, rel_err, sheba_forcing
+from tests.oracle_lib import oracle_solver
+from tests.test_oracle_golden import _restore_midstep
+
+pytestmark = pytest.mark.gpu
+
+NTHREADS = min(16, len(os.sched_getaffinity(0)))
+
+
+def _pair(cfg, ncol, st, forcing=None):
+    g = samsim_amd.hip_solver(cfg, ncol)
+    o = oracle_solver(cfg, ncol)
+    o.set_threads(NTHREADS)
+    for s in (g, o):
+        if forcing is not None:
+            s.set_forcing(*forcing, *tcs.ensemble_perturbation(ncol))
+        s.set_state(st)
+        s.set_clock()
+    return g, o
+
+
+def _check(g, o, what, rtol=RTOL):
+    assert np.array_equal(g.get_status()[0], o.get_status()[0]), f"{what}: STOP codes differ"
+    sg, so = g.get_state(), o.get_state()
+    assert_state_close(sg, so, rtol, what=what)
+    return sg, so
+
+
+def _teacher_forced(g, o, total_steps, every, window, what, rtol=RTOL):
+    """advance the oracle to `total_steps`; every `every` steps restart the HIP path from the oracle's state and require
+    agreement `window` steps later (the melt seasons amplify round-off in a free run)"""
+    seen, snow = set(), []
+    while o.get_clock().step + every <= total_steps:
+        k = o.get_clock()
+        g.set_state(o.get_state())
+        g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+        g.step(window)
+        o.step(window)
+        _, so = _check(g, o, f"{what}: window at step {k.step}", rtol)
+        seen.update(int(v) for v in so.n_active)
+        snow.append(float(so.sc("thick_snow").max()))
+        o.step(every - window)
+    return seen, snow
+
+
+def test_tc3_notz_fluxes_and_constant_snowfall():
+    """testcase 3: free run from open water through the first 140 days against the oracle and against the reference's
+    own output records, then teacher-forced windows through both melt seasons of the 756-day run"""
+    ncol = 16
+    cfg, st = tcs.testcase3(ncol)
+    g, o = _pair(cfg, ncol, st)
+    ref = golden("tc3_ref_fullprec.npz")
+    g.set_output_window(0, 1)
+    for i in range(40):
+        out = g.run_to_output()
+        assert out.step == ref["step"][i] and out.n_active[0] == ref["N_active"][i], f"output {i}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick"]:
+            assert rel_err(out.arr(n)[:na, 0], ref["a_" + n][i, :na], 1e-7) <= RTOL, f"output {i}: {n} vs reference"
+        for n, floor in (("thick_snow", 1e-7), ("T_snow", 1e-2), ("T_top", 1e-2), ("freeboard", 1e-7), ("thickness", 1e-7)):
+            assert rel_err(out.sc(n)[0], ref["s_" + n][i], floor) <= RTOL, f"output {i}: {n} vs reference"
+    o.step(g.get_clock().step)
+    sg, so = _check(g, o, "tc3 day 140")
+    assert so.sc("thick_snow").min() > 0.01 and int(so.n_active[0]) > 5
+    assert sg.sc("fl_rest")[0] == so.sc("fl_rest")[0] > 179.0          # sub_notzflux ran on both sides
+    seen, snow = _teacher_forced(g, o, tcs.i_time(cfg), every=30240, window=3000, what="tc3")
+    assert min(snow) < 1e-3 and max(snow) > 0.1, (seen, snow)     # windows in snow-covered winter and bare-ice summer
+
+
+def test_tc5_fixed_fluxes_flushing_of_a_slab():
+    """testcase 5: every layer active from the start, salinity reset at step 2, constant fluxes, flushing (flush3) melts the
+    1 m slab down to a few layers; free run over the first 20 000 steps, then teacher-forced windows to the end"""
+    ncol = 16
+    cfg, st = tcs.testcase5(ncol)
+    g, o = _pair(cfg, ncol, st)
+    done = 0
+    for upto in (1, 2, 3, 1080, 1081, 20000):
+        g.step(upto - done)
+        o.step(upto - done)
+        done = upto
+        sg, so = _check(g, o, f"tc5 step {upto}")
+        if upto == 2:
+            assert np.allclose(sg.arr("S_abs"), 5.0 * sg.arr("m"), rtol=1e-12, atol=0)    # mo_grotz.f90:543-544
+    seen, _ = _teacher_forced(g, o, tcs.i_time(cfg), every=10800, window=2500, what="tc5", rtol=1e-6)
+    assert min(seen) < 30 and max(seen) == 100, seen
+
+
+def test_tc7_simple_parametrisations_free_run_and_reference_windows():
+    """testcase 7: perturbed ensemble through open water, freeze-up and the first days of growth (grav_flag 3 acting), then
+    12-hour windows restarted from the REFERENCE's own mid-step states (fixture) through growth, the melt season with
+    flush_flag 4, and refreeze: HIP vs oracle at the parity bar, and HIP vs the reference's next record."""
+    ncol = 16
+    cfg, st = tcs.testcase7(ncol)
+    g, o = _pair(cfg, ncol, st, forcing=sheba_forcing())
+    for n in (1, 560000, 30000):
+        g.step(n)
+        o.step(n)
+        sg, so = _check(g, o, f"tc7 free run to step {o.get_clock().step}")
+    assert so.n_active.max() > 5
+
+    ref = golden("tc7_ref_fullprec.npz")
+    cfg1, _ = tcs.testcase7(1)
+    g = samsim_amd.hip_solver(cfg1, 1)
+    o = oracle_solver(cfg1, 1)
+    for s in (g, o):
+        s.set_forcing(*sheba_forcing())
+    g.set_output_window(0, 1)
+    for p, idx in enumerate(ref["tf_index"]):
+        _restore_midstep(o, ref, 2 * p, cfg1)
+        o.step_part_b()                                   # finish the reference's step: now at a step boundary
+        k = o.get_clock()
+        g.set_state(o.get_state())
+        g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+        og, oo = g.run_to_output(), o.run_to_output()
+        j = 2 * p + 1
+        assert og.step == oo.step == ref["tf_step"][j] and og.n_active[0] == ref["tf_N_active"][j], f"window {idx}"
+        na = int(og.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+            floor = 1e-3 if n == "H_abs" else 1e-7
+            assert rel_err(og.arr(n)[:na, 0], ref["tf_a_" + n][j, :na], floor) <= RTOL, f"window {idx}: {n} vs reference"
+        for n, floor in (("m_snow", 1e-5), ("thick_snow", 1e-7), ("T_snow", 1e-2), ("T_top", 1e-2), ("freeboard", 1e-7),
+                         ("thickness", 1e-7)):
+            assert rel_err(og.sc(n)[0], ref["tf_s_" + n][j], floor) <= RTOL, f"window {idx}: {n} vs reference"
+        _check(g, o, f"tc7 window {idx}")
+
+
+def test_flood_simple_under_heavy_snow():
+    """flood_flag 3 never fires in the reference's own testcase-7 run (the freeboard stays above -5 cm), so it is driven
+    here: a winter state of that run is loaded with 1.3 m of cold snow, which pushes the freeboard below neg_free and
+    makes flood_simple convert snow to slush every step until the column floats again"""
+    ref = golden("tc7_ref_fullprec.npz")
+    p = int(np.where(ref["tf_index"] == 400)[0][0])
+    cfg, _ = tcs.testcase7(1)
+    o = oracle_solver(cfg, 1)
+    o.set_forcing(*sheba_forcing())
+    _restore_midstep(o, ref, 2 * p, cfg)
+    o.step_part_b()
+    st, k = o.get_state(), o.get_clock()
+    st.sc("thick_snow")[:] = 1.3
+    st.sc("m_snow")[:] = 1.3 * tcs.RHO_SNOW
+    st.sc("H_abs_snow")[:] = -st.sc("m_snow") * (tcs.LATENT_HEAT + 2020.0 * 15.0)
+    st.sc("psi_s_snow")[:] = tcs.RHO_SNOW / 920.0
+    st.sc("psi_g_snow")[:] = 1.0 - tcs.RHO_SNOW / 920.0
+    st.sc("T_snow")[:] = -15.0
+    ncol = 8
+    g = samsim_amd.hip_solver(cfg, ncol)
+    o = oracle_solver(cfg, ncol)
+    for s in (g, o):
+        s.set_forcing(*sheba_forcing(), *tcs.ensemble_perturbation(ncol))
+        s.set_state(st.replicate(ncol))
+        s.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+    snow0 = float(st.sc("thick_snow")[0])
+    for n in (1, 1, 10, 500):
+        g.step(n)
+        o.step(n)
+        sg, so = _check(g, o, f"flood_simple +{n}")
+    assert so.sc("thick_snow").max() < snow0 - 0.05, "flood_simple did not fire"
