@@ -47,12 +47,26 @@ constexpr double emissivity_ice = 0.95, emissivity_snow = 1.00, penetr = 0.30, e
 constexpr double Turb_A = 0.1 * 0.05 * rho_l / 86400.0;
 constexpr double Turb_B = 0.05;
 
-// Functions off the common path (snow, flooding, flushing, regridding, output, the unfused sweeps) can be kept out of
-// line (tuning knob SAMSIM_OUTLINE_RARE, off: measured slower because the column struct then lives in scratch).
-#if defined(SAMSIM_OUTLINE_RARE) && SAMSIM_OUTLINE_RARE
-#define RARE __attribute__((noinline))
+// Every device function that takes the column struct or the context by reference is force-inlined: if one of them stayed
+// out of line the struct would escape, its fields would live in scratch memory, the data pointers in it would lose their
+// address space and the (uniform) config reads would become vector loads.  Measured: out-of-line rare paths by reference
+// 101 ms, by value (struct copied in and out) 209 ms, everything inline 90 ms per launch of the default bench.
+#define RARE __forceinline__
+
+// Device data pointers carry the global address space in their type: an access through them is a global_load / global_store
+// even where the pointer itself has been through memory (a struct passed to a non-inlined function), where the compiler
+// would otherwise have to assume a generic (flat) address.
+#ifndef SAMSIM_AS1
+#define SAMSIM_AS1 1
+#endif
+#if SAMSIM_AS1
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const double gcdouble;
+typedef __attribute__((address_space(1))) int32_t gint32;
 #else
-#define RARE
+typedef double gdouble;
+typedef const double gcdouble;
+typedef int32_t gint32;
 #endif
 
 struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
@@ -60,13 +74,13 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 };
 
 struct Col {
-  double *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
+  gdouble *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
   unsigned col; // this lane's column: 32-bit, so that an access is <scalar row base> + <one 32-bit lane offset>
   size_t ncol;
   int N;
   int Na;       // N_active
   int flags;          // COLF_*
-  double *spec;       // [DEV_NSPEC] hand-over block, already offset by the column index
+  gdouble *spec;       // [DEV_NSPEC] hand-over block, already offset by the column index
   int status, err_layer;
   long long err_step;
   long long step;  // completed steps; i = step + 1
@@ -121,6 +135,14 @@ __device__ __forceinline__ int wave_max(int v) {
 
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+// S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594.  (Forming them, Expulsion's quotients and the
+// Newton terms through shared reciprocals removes a third of the FP64 divisions and changes nothing in the launch time:
+// the sweeps wait on memory, not on the VALU.  The reference's quotients are kept.)
+__device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
+  S_bu = S_abs / m;
+  H = H_abs / m;
+}
+__device__ __forceinline__ double per_mass(double S_abs, double m) { return S_abs / m; }
 
 // func_S_br without / with the S_bu clamp, mo_thermo_functions.f90:308-360.  flang lowers T**2._wp and T**3._wp
 // to multiplications (verified bit for bit against the flang build), so do we.
@@ -137,9 +159,17 @@ __device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
   return d;
 }
 
+// residual f(T_0) and its derivative of the enthalpy relation, mo_thermo_functions.f90:95-96 / :109-110 (the first evaluation
+// clamps S_br at 1e-9, the ones in the loop at 1e-10, as in the reference)
+__device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_bu, double T_0, double sb, double sb_floor,
+                                             double &f, double &ddT_f) {
+  f = -latent_heat - H + latent_heat * S_bu / dmax(sb, sb_floor) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
+  ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+}
+
 // getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
 // Returns 99 (the reference's STOP code) when 260 iterations do not converge.
-__device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out) {
+__device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out) {
   double T = H / c_l, phi = phi_out;
   int rc = 0;
   if (S_br_clamped(s, T, S_bu) > S_bu && S_bu > 0.001) {
@@ -147,8 +177,7 @@ __device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T
     bool have_T_fr = false;
     T_0 = T_in;
     sb = S_br_poly(s, T_0);
-    f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
-    ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+    newton_terms(s, H, S_bu, T_0, sb, 0.000000001, f, ddT_f);
     T = T_0 - f / ddT_f;
     int i = 0;
     while (fabs(f) > 1.0) {
@@ -167,8 +196,7 @@ __device__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T
         T_0 = T_fr;
       }
       sb = S_br_poly(s, T_0);
-      f = -latent_heat - H + latent_heat * S_bu / dmax(sb, 0.0000000001) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
-      ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+      newton_terms(s, H, S_bu, T_0, sb, 0.0000000001, f, ddT_f);
       T = T_0 - f / ddT_f;
       if (++i == 260) { rc = 99; break; }
     }
@@ -242,14 +270,15 @@ struct Ctx {
   const DevParams *p;
   // The data pointers are taken from DIRECT kernel arguments, not from the parameter block: only then does the compiler
   // know they are global-memory pointers (global_load/global_store with scalar base) instead of generic flat ones.
-  const double *f_sw, *f_lw, *f_T2m, *f_precip;
-  double *out_lay, *out_scal;
-  double *scal;  // [SAMSIM_NSCAL][ncol] scalar block: slots that are not carried in registers (fl_rest) are read / written in place
-  int32_t *out_n_active;
+  gcdouble *f_sw, *f_lw, *f_T2m, *f_precip;
+  gdouble *out_lay, *out_scal;
+  gdouble *scal;  // [SAMSIM_NSCAL][ncol] scalar block: slots that are not carried in registers (fl_rest) are read / written in place
+  gint32 *out_n_active;
   long long out_col0, out_ncols;
   Salt salt;
   double p17, p14, tf_c3;
 };
+
 
 // ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
 // O(N): one pass for the column totals, one pass for the waterline search with prefix sums (the reference
@@ -338,8 +367,9 @@ __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
   if (rc) STOPC(rc == 16 ? 16 : 99, 1);
 }
 
+
 // snow_precip (mo_snow.f90:123-150) and snow_precip_0 (:167-192), called from mo_grotz.f90:251-265
-__device__ void snow_fall(Col &c, const Ctx &x) {
+__device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   if (!(dmax(c.liquid_precip, c.solid_precip) > 0.0)) return;
   const double dt = g.dt, T2m = c.T2m;
@@ -550,7 +580,8 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
       S_abs = 0.0;
       LAY(SAMSIM_A_S_ABS, k) = S_abs;
     }
-    const double S_bu = S_abs / m, H = H_abs / m;
+    double S_bu, H;
+    per_mass(S_abs, H_abs, m, S_bu, H);
     double T, phi = 0.0;
     int rr = getT(s, H, S_bu, T_test, T, phi);
     if (rr && !rc) { rc = rr; rc_layer = k; }
@@ -567,7 +598,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
 
 // Layer 1 of the first sweep when layers N_active..2 were already done by the previous step's up sweep
 // (their prognostic values have not changed since).  The scan state comes from the hand-over block.
-__device__ void prologue_top_layer(Col &c, const Ctx &x) {
+__device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const size_t nc = c.ncol;
@@ -579,7 +610,8 @@ __device__ void prologue_top_layer(Col &c, const Ctx &x) {
   const double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1);
   double S_abs = LAY(SAMSIM_A_S_ABS, 1);
   if (S_abs < 0.0) { S_abs = 0.0; LAY(SAMSIM_A_S_ABS, 1) = S_abs; }
-  const double S_bu = S_abs / m, H = H_abs / m;
+  double S_bu, H;
+  per_mass(S_abs, H_abs, m, S_bu, H);
   const double T_test = (Na > 1) ? LAY(SAMSIM_A_T, 2) : g.T_bottom;
   double T, phi = 0.0;
   const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
@@ -626,7 +658,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
     // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
     const double T = LAY(SAMSIM_A_T, k);
-    const double S_br = S_br_clamped(x.salt, T, S_abs / m_in);
+    const double S_br = S_br_clamped(x.salt, T, per_mass(S_abs, m_in));
     LAY(SAMSIM_A_S_BR, k) = S_br;
     if (transfer) {
       double H_abs = 0.0;
@@ -926,7 +958,7 @@ __device__ RARE void sweep_beer(Col &c, double beer0) {
 // A(j) of the reference runs for all layers before B starts, but A(j) only reads layers <= j and B/C(j-1) only layers
 // j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
 // T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
-__device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0) {
+__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -941,7 +973,7 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
     r.T = LAY(SAMSIM_A_T, j);
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.m = LAY(SAMSIM_A_M, j);
-    r.S_br = S_br_clamped(s, r.T, r.S_abs / r.m);  // S_br(j) of the first sweep
+    r.S_br = S_br_clamped(s, r.T, per_mass(r.S_abs, r.m));  // S_br(j) of the first sweep
     return r;
   };
   struct Lay { double T, S_bu, S_abs, H_abs, m, flup; };
@@ -1067,11 +1099,14 @@ __device__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer
 
 // ---------------------------------------------------------------- surface energy balance, mo_heat_fluxes.f90:77-195
 // sets fl_Q(1), T_top, fl_Q_snow, albedo, fl_sw, fl_lw, T_freeze; returns the Beer-law surface value temp2
-__device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
+// GEN = false: the instantiation for the primary configurations (forcing tables or cooling plate, grav_flag 1/2, flush_flag
+// 1/5, flood_flag 1/2, testcases without layer-array specifics); the secondary parametrisations compile away there.
+template <bool GEN>
+__device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (g.boundflux_flag != 2) return 0.0;
   c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, g.albedo_flag);
-  if (g.atmoflux_flag == 2) {
+  if (!GEN || g.atmoflux_flag == 2) {
     if (time == time_input(tc)) {
       c.fl_sw = x.f_sw[tc - 1];
       c.fl_lw = x.f_lw[tc - 1];
@@ -1094,7 +1129,8 @@ __device__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   return pen * (1.0 - c.albedo) * c.fl_sw;
 }
 
-__device__ void surface_flux(Col &c, const Ctx &x) {
+template <bool GEN>
+__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
@@ -1108,7 +1144,7 @@ __device__ void surface_flux(Col &c, const Ctx &x) {
   }
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
-  const double fl_rest = (g.atmoflux_flag == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
+  const double fl_rest = (!GEN || g.atmoflux_flag == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
   double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
@@ -1151,76 +1187,6 @@ __device__ void surface_flux(Col &c, const Ctx &x) {
   }
 }
 
-// ---------------------------------------------------------------- P4: heat + second thermodynamic sweep, bottom -> top
-// mo_heat_fluxes.f90:262-310 (stencil fl_Q(k) = (T_k - T_{k-1}) / (thick_{k-1}/2k_{k-1} + thick_k/2k_k), explicit
-// H_abs update, fl_rad(N_active) added to EVERY layer, snow enthalpy, energy assert) fused with the getT sweep
-// of mo_grotz.f90:592-598: fl_Q(k) only needs the OLD temperatures of k-1 and k, so the freshly updated H_abs(k)
-// feeds the Newton chain directly.
-__device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
-  const samsim_config &g = x.p->cfg;
-  const Salt &s = x.salt;
-  const int Na = c.Na;
-  const double dt = g.dt, thick_min = g.thick_min;
-  const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
-  const double H_abs_snow_before = c.H_abs_snow;
-  double sum_before = 0.0, sum_after = 0.0;
-  double flq_below = c.fl_q_bottom;  // fl_Q(k+1)
-  double T_test = g.T_bottom;
-  int rc = 0, rc_layer = 0;
-  // layer k (old values)
-  double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
-  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
-  for (int k = Na; k >= 1; --k) {
-    double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
-    if (k > 1) {
-      T_u = LAY(SAMSIM_A_T, k - 1);
-      th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
-      const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
-      flq_k = (T_k - T_u) / R;
-    } else {
-      flq_k = c.fl_Q1;
-    }
-    double H_abs = LAY(SAMSIM_A_H_ABS, k);
-    sum_before += H_abs;
-    H_abs = H_abs + (flq_below - flq_k) * dt;
-    H_abs = H_abs + c.frad * dt;
-    const double m = LAY(SAMSIM_A_M, k);
-    if (k == 1) {  // snow treatment, mo_heat_fluxes.f90:291-303
-      if (thin_snow) {
-        c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
-        LAY(SAMSIM_A_H_ABS, 1) = H_abs;
-        snow_coupling(c, x);
-        if (c.status) return;
-        H_abs = LAY(SAMSIM_A_H_ABS, 1);
-      } else if (c.thick_snow >= thick_min) {
-        c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
-      }
-    }
-    sum_after += H_abs;
-    LAY(SAMSIM_A_H_ABS, k) = H_abs;
-    const double S_bu = LAY(SAMSIM_A_S_ABS, k) / m, H = H_abs / m;
-    double T, phi = 0.0;
-    int r = getT(s, H, S_bu, T_test, T, phi);
-    if (r && !rc) { rc = r; rc_layer = k; }
-    T_test = T;
-    LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_PHI, k) = phi;
-    LAY(SAMSIM_A_S_BU, k) = S_bu;
-    flq_below = flq_k;
-    T_k = T_u; th_k = th_u; kk_k = kk_u;
-  }
-  // energy conservation assert, mo_heat_fluxes.f90:265-310
-  double temp1 = sum_before + H_abs_snow_before;
-  temp1 = temp1 + (double)Na * (c.frad * dt);
-  if (thin_snow || c.thick_snow >= thick_min) temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
-  else temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q1 * dt;
-  const double temp2 = sum_after + c.H_abs_snow;
-  if (rc) STOPC(rc, rc_layer);
-  if (fabs((temp1 - temp2) / dt) > 0.00001) STOPC(431, 0);
-}
-
 // ---------------------------------------------------------------- U: fused up sweep (P4 + next step's S1), bottom -> top
 // sweep_heat_thermo plus, for layers N_active..2, the first sweep of the NEXT time step: that sweep would divide the
 // same H_abs by the same m and start Newton from the same guesses (T_bottom, then the layer below), so its T and phi
@@ -1229,7 +1195,7 @@ __device__ void sweep_heat_thermo(Col &c, const Ctx &x) {
 // freeboard, flush3) still need the current ones.  Layer 1 is left to prologue_top_layer: snow, melt water and the
 // regrid trigger all act on it between the two steps.  If flushing or a regrid changes deeper layers afterwards, the
 // column is flagged COLF_DIRTY and the next step runs the full first sweep instead.
-__device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output) {
+__device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -1252,16 +1218,17 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  double kk_k = LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l;
+  // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
+  double hr_k = th_k / (2.0 * (LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l));  // half resistance of layer k: the same quotient serves fl_Q(k+1) and fl_Q(k)
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
-    double flq_k, T_u = 0.0, th_u = 0.0, kk_u = 0.0;
+    double flq_k, T_u = 0.0, th_u = 0.0, hr_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      kk_u = LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l;
-      const double R = th_u / (2.0 * kk_u) + th_k / (2.0 * kk_k);  // sub_fl_Q, mo_thermo_functions.f90:201-223
+      hr_u = th_u / (2.0 * (LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l));
+      const double R = hr_u + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
       flq_k = c.fl_Q1;
@@ -1285,7 +1252,8 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
     sum_after += H_abs;
     LAY(SAMSIM_A_H_ABS, k) = H_abs;
     double S_abs = LAY(SAMSIM_A_S_ABS, k);
-    const double S_bu = S_abs / m, H = H_abs / m;
+    double S_bu, H;
+    per_mass(S_abs, H_abs, m, S_bu, H);
     double T, phi = 0.0;
     int rr = getT(s, H, S_bu, T_test, T, phi);
     if (rr && !rc) { rc = rr; rc_layer = k; }
@@ -1302,7 +1270,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
       s1_layer(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
     }
     flq_below = flq_k;
-    T_k = T_u; th_k = th_u; kk_k = kk_u;
+    T_k = T_u; th_k = th_u; hr_k = hr_u;
   }
   // hand-over block for prologue_top_layer of the next step
   c.spec[SP_MINP * nc] = r.minp; c.spec[SP_STP * nc] = r.stp; c.spec[SP_ST * nc] = r.st;
@@ -1319,7 +1287,7 @@ __device__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is
 }
 
 // ---------------------------------------------------------------- melt film, mo_functions.f90:386-474
-__device__ void sub_melt_thick(double psi_l, double psi_s, double psi_g, double T, double T_freeze, double T_top, double fl_Q,
+__device__ __forceinline__ void sub_melt_thick(double psi_l, double psi_s, double psi_g, double T, double T_freeze, double T_top, double fl_Q,
                                double thick_snow, double dt, double &melt_thick, double &thick, double thick_min) {
   melt_thick = 0.0;
   if (thick_snow < thick_min && T_top >= T_freeze) {
@@ -1472,7 +1440,7 @@ __device__ __forceinline__ void zero_layer(Col &c, int k) {
 }
 
 // top_melt, mo_layer_dynamics.f90:191-327
-__device__ void top_melt(Col &c, const Ctx &x) {
+__device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thick_0 = g.thick_0;
@@ -1517,7 +1485,7 @@ __device__ void top_melt(Col &c, const Ctx &x) {
 }
 
 // top_grow, mo_layer_dynamics.f90:607-716
-__device__ void top_grow(Col &c, const Ctx &x) {
+__device__ __forceinline__ void top_grow(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thick_0 = g.thick_0;
@@ -1561,7 +1529,7 @@ __device__ void top_grow(Col &c, const Ctx &x) {
 }
 
 // bottom_melt, mo_layer_dynamics.f90:341-427 (N_active == Nlayer)
-__device__ void bottom_melt(Col &c, const Ctx &x) {
+__device__ __forceinline__ void bottom_melt(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thN = LAY(SAMSIM_A_THICK, N);
@@ -1589,7 +1557,7 @@ __device__ void bottom_melt(Col &c, const Ctx &x) {
 }
 
 // bottom_growth, mo_layer_dynamics.f90:438-523 (N_active == Nlayer)
-__device__ void bottom_growth(Col &c, const Ctx &x) {
+__device__ __forceinline__ void bottom_growth(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle, N_bottom = g.n_bottom;
   const double thN = LAY(SAMSIM_A_THICK, N);
@@ -1652,7 +1620,9 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   }
 }
 
+
 // ---------------------------------------------------------------- output snapshot, mo_grotz.f90:340-398
+template <bool GEN>
 __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double time) {
   const samsim_config &g = x.p->cfg;
   if (c.Na > 1) c.freeboard = func_freeboard(c, x); else c.freeboard = 0.0;
@@ -1671,7 +1641,7 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
         x.out_lay[((size_t)a * c.N + (k - 1)) * on + oc] = v;
       }
     }
-    double *o = x.out_scal + oc;
+    gdouble *o = x.out_scal + oc;
 #define OUT(idx, v) o[(size_t)(idx) * on] = (v)
     OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
     OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
@@ -1685,7 +1655,7 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
-    OUT(SAMSIM_S_FL_REST, (g.atmoflux_flag == 2 && g.boundflux_flag == 2) ? c.fl_lw + 0.0 + 0.0
+    OUT(SAMSIM_S_FL_REST, (g.boundflux_flag == 2 && (!GEN || g.atmoflux_flag == 2)) ? c.fl_lw + 0.0 + 0.0
                                                                         : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
     OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
 #undef OUT
@@ -1697,12 +1667,13 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
 }
 
 // testcase specifics that only touch scalars, mo_grotz.f90:503-565
+template <bool GEN>
 __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g, double time) {
   if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
     for (int n = 1; n <= 20; ++n) {
       if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
     }
-  } else if (g.testcase == 3) {  // sub_test3, :172-187
+  } else if (GEN && g.testcase == 3) {  // sub_test3, :172-187
     c.liquid_precip = 0.0;
     c.solid_precip = 0.15 / 86400.0 / 356.0;
   } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
@@ -1710,8 +1681,80 @@ __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g,
   }
 }
 
+// The reference's order between expulsion and the heat fluxes, sweep by sweep: taken whenever something sits between
+// expulsion and gravity drainage (the output block, thin-snow coupling, a possible flooding event) or no Rayleigh-number
+// drainage runs at all; mo_grotz.f90:312-565.
+template <bool GEN>
+__device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool coupling,
+                                  bool do_grav, bool do_beer) {
+  const samsim_config &g = x.p->cfg;
+  const int N = c.N, Na = c.Na;
+    sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
+
+    if (out_step) output_point<GEN>(c, x, col, time);  // mo_grotz.f90:340-398
+
+    // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
+    {
+      const double psi_gN = LAY(SAMSIM_A_PSI_G, Na);
+      if (psi_gN > 0.0) {
+        const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
+        LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
+        LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
+        LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
+      }
+    }
+    // thin-snow coupling, mo_grotz.f90:418-420
+    if (coupling) {
+      snow_coupling(c, x);
+      if (c.status) return;
+    }
+    // flooding, mo_grotz.f90:428-445
+    if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
+      // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
+      // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
+      const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
+      if (c.m_snow > buoy) {
+        c.freeboard = (buoy - c.m_snow) / rho_l;
+        if (c.freeboard < 0.0 && g.flood_flag == 2) {
+          flood(c, x);
+          if (g.grav_flag >= 2) refresh_ray_top(c, x);
+        } else if (GEN && g.flood_flag == 3 && c.freeboard < neg_free) {
+          flood_simple(c, x);
+          if (g.grav_flag >= 2) refresh_ray_top(c, x);
+        }
+      }
+    }
+    // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
+    if (g.turb_flag == 2) {
+      const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
+      double S_abs = LAY(SAMSIM_A_S_ABS, Na);
+      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
+      S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+      LAY(SAMSIM_A_S_ABS, Na) = S_abs;
+    }
+
+    // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
+    testcase_scalars<GEN>(c, g, time);
+
+    // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
+    const double beer0 = radiation_header<GEN>(c, x, time, tc);
+    c.frad = 0.0;
+    if (do_grav) {
+      sweep_grav_drain(c, x, do_beer, beer0);
+      if (c.status) return;
+    } else if (GEN && g.grav_flag == 3 && Na > 1) {
+      sweep_grav_drain_simple(c, do_beer, beer0);
+    } else if (do_beer) {
+      sweep_beer(c, beer0);
+    }
+    if (GEN && g.testcase == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
+      for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
+    }
+}
+
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
-__device__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
+template <bool GEN>
+__device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N;
 
@@ -1759,82 +1802,23 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   const bool flood_possible = (g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0 &&
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
-                     !(g.testcase == 5 && c.step + 1 == 2);
+                     !(GEN && g.testcase == 5 && c.step + 1 == 2);
 
   if (fused) {
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
-    testcase_scalars(c, g, time);
-    const double beer0 = radiation_header(c, x, time, tc);
+    testcase_scalars<GEN>(c, g, time);
+    const double beer0 = radiation_header<GEN>(c, x, time, tc);
     c.frad = 0.0;
     sweep_down_fused(c, x, do_beer, beer0);
     if (c.status) return;
   } else {
-    sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
-
-    if (out_step) output_point(c, x, col, time);  // mo_grotz.f90:340-398
-
-    // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
-    {
-      const double psi_gN = LAY(SAMSIM_A_PSI_G, Na);
-      if (psi_gN > 0.0) {
-        const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
-        LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
-        LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
-        LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
-      }
-    }
-    // thin-snow coupling, mo_grotz.f90:418-420
-    if (coupling) {
-      snow_coupling(c, x);
-      if (c.status) return;
-    }
-    // flooding, mo_grotz.f90:428-445
-    if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
-      // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
-      // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
-      const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
-      if (c.m_snow > buoy) {
-        c.freeboard = (buoy - c.m_snow) / rho_l;
-        if (c.freeboard < 0.0 && g.flood_flag == 2) {
-          flood(c, x);
-          if (g.grav_flag >= 2) refresh_ray_top(c, x);
-        } else if (g.flood_flag == 3 && c.freeboard < neg_free) {
-          flood_simple(c, x);
-          if (g.grav_flag >= 2) refresh_ray_top(c, x);
-        }
-      }
-    }
-    // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
-    if (g.turb_flag == 2) {
-      const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
-      double S_abs = LAY(SAMSIM_A_S_ABS, Na);
-      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
-      S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
-      LAY(SAMSIM_A_S_ABS, Na) = S_abs;
-    }
-
-    // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
-    testcase_scalars(c, g, time);
-
-    // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
-    const double beer0 = radiation_header(c, x, time, tc);
-    c.frad = 0.0;
-    if (do_grav) {
-      sweep_grav_drain(c, x, do_beer, beer0);
-      if (c.status) return;
-    } else if (g.grav_flag == 3 && Na > 1) {
-      sweep_grav_drain_simple(c, do_beer, beer0);
-    } else if (do_beer) {
-      sweep_beer(c, beer0);
-    }
-    if (g.testcase == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
-      for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
-    }
+    down_unfused<GEN>(c, x, col, time, tc, out_step, coupling, do_grav, do_beer);
+    if (c.status) return;
   }
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
-  surface_flux(c, x);
+  surface_flux<GEN>(c, x);
   sweep_up_fused(c, x, col, next_out);
   if (c.status) return;
 
@@ -1889,7 +1873,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
 
   // flushing, mo_grotz.f90:670-737
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
-  const bool flush_possible = ((g.flush_flag == 5 || g.flush_flag == 4) && Na > 2 &&
+  const bool flush_possible = ((g.flush_flag == 5 || (GEN && g.flush_flag == 4)) && Na > 2 &&
                                c.melt_thick + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !fb_valid) c.freeboard = func_freeboard(c, x);
   c.melt_out1 = c.melt_out1 + c.melt_thick;
@@ -1907,7 +1891,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
   }
   if (flush_possible && c.freeboard > 0.001) {
     if (c.melt_thick > 0.000000000001) {
-      if (g.flush_flag == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
+      if (GEN && g.flush_flag == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
         const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
         LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - c.melt_thick * rho_l * c_l * T1;
         LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (c.melt_thick * rho_l) / m1);
@@ -1958,6 +1942,7 @@ __device__ void column_step(Col &c, const Ctx &x, long long col, double time, in
 #ifndef SAMSIM_WAVES
 #define SAMSIM_WAVES 1
 #endif
+template <bool GEN>
 __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel(const DevParams *__restrict__ pp, double *__restrict__ lay, double *__restrict__ scal,
                                                                         double *__restrict__ spec, int32_t *__restrict__ n_active,
                                                                         int32_t *__restrict__ status, int32_t *__restrict__ err_layer,
@@ -1971,16 +1956,16 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   if (col >= p.ncol) return;
   Ctx x;
   x.p = pp;
-  x.f_sw = f_sw; x.f_lw = f_lw; x.f_T2m = f_T2m; x.f_precip = f_precip;
-  x.out_lay = out_lay; x.out_scal = out_scal; x.out_n_active = out_n_active;
-  x.scal = scal;
+  x.f_sw = (gcdouble *)f_sw; x.f_lw = (gcdouble *)f_lw; x.f_T2m = (gcdouble *)f_T2m; x.f_precip = (gcdouble *)f_precip;
+  x.out_lay = (gdouble *)out_lay; x.out_scal = (gdouble *)out_scal; x.out_n_active = (gint32 *)out_n_active;
+  x.scal = (gdouble *)scal;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   if (p.cfg.salt_flag == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
   Col c;
-  c.lay = lay;
+  c.lay = (gdouble *)lay;
   c.col = (unsigned)col;
   c.ncol = (size_t)p.ncol;
   c.N = p.cfg.nlayer;
@@ -1990,7 +1975,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.err_step = err_step[col];
   c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
-  c.spec = spec + col;
+  c.spec = (gdouble *)spec + col;
   const size_t nc = (size_t)p.ncol;
   double *sc = scal + col;
 #define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
@@ -2025,7 +2010,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
-      column_step(c, x, col, time, tc, out_step, next_out);
+      column_step<GEN>(c, x, col, time, tc, out_step, next_out);
     }
     time = time + p.cfg.dt;
     step = step + 1;
@@ -2052,7 +2037,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SSTORE(thickness, SAMSIM_S_THICKNESS); SSTORE(bulk_salin, SAMSIM_S_BULK_SALIN);
 #undef SSTORE
   // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112
-  if (p.cfg.atmoflux_flag == 2 && p.cfg.boundflux_flag == 2) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
+  if (p.cfg.boundflux_flag == 2 && (!GEN || p.cfg.atmoflux_flag == 2)) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
 }
 
 }  // namespace
@@ -2061,7 +2046,11 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
 extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, hipStream_t stream) {
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
-  hipLaunchKernelGGL(samsim_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
+  const samsim_config &g = hp->cfg;
+  const bool general = (g.boundflux_flag == 2 && g.atmoflux_flag != 2) || g.grav_flag == 3 || g.flush_flag == 4 ||
+                       g.flood_flag == 3 || g.testcase == 3 || g.testcase == 5;
+  auto kernel = general ? samsim_step_kernel<true> : samsim_step_kernel<false>;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
                      hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active);
   return hipGetLastError();
