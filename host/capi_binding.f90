@@ -50,6 +50,11 @@ MODULE mo_samsim_capi
      INTEGER(c_int64_t) :: step
   END TYPE samsim_output_soa
 
+  TYPE, BIND(C) :: samsim_stat               ! samsim_stat: ensemble statistics of one per-column scalar
+     INTEGER(c_int64_t) :: count
+     REAL(c_double)     :: mean, min, max, std
+  END TYPE
+
   INTERFACE
      INTEGER(c_int) FUNCTION samsim_create(cfg, ncol, device, h) BIND(C, name='samsim_create')
        IMPORT
@@ -113,6 +118,13 @@ MODULE mo_samsim_capi
        INTEGER(c_int32_t), INTENT(out) :: status(*)
        INTEGER(c_int64_t), INTENT(out) :: step(*)
        INTEGER(c_int32_t), INTENT(out) :: layer(*)
+     END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_get_ensemble_stats(h, nslots, slots, out) BIND(C, name='samsim_get_ensemble_stats')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       INTEGER(c_int32_t), VALUE :: nslots
+       INTEGER(c_int32_t), INTENT(in) :: slots(*)        ! enum samsim_scalar values (0-based), -1 = N_active
+       TYPE(samsim_stat), INTENT(out) :: out(*)
      END FUNCTION
      INTEGER(c_int) FUNCTION samsim_get_work(h, cells, colsteps) BIND(C, name='samsim_get_work')
        IMPORT

@@ -4,7 +4,7 @@
 !! runs on the GPU behind the C-ABI of include/samsim.h for `ncol` columns at once.
 !!
 !! New surface the reference does not have (SURVEY.md, introduction): a namelist file `samsim.nml`
-!!   &samsim_run   testcase, ncol, device, out_col, perturb, description, max_steps /
+!!   &samsim_run   testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out /
 !!   &samsim_flags <any flag of mo_data.f90:136-155 or scalar set by mo_init> /       (overrides init(testcase))
 !! `dat_settings.dat` stays the echo of what was actually used.
 !!
@@ -16,6 +16,7 @@ MODULE mo_data
   IMPLICIT NONE
   INTEGER, PARAMETER :: wp = SELECTED_REAL_KIND(12, 307)   ! mo_parameters.f90:33
   REAL(wp), PARAMETER :: rho_l = 1028.0_wp, c_l = 3400._wp, k_s = 2.2_wp, rho_s = 920._wp, c_s = 2020.0_wp
+  INTEGER(c_int64_t), PARAMETER :: restart_magic = INT(z'31304B48434D4153', c_int64_t)   ! the bytes "SAMCHK01"
   REAL(wp), PARAMETER :: sigma = 5.6704_wp*1e-8   !< Stefan Boltzmann constant as written in mo_parameters.f90:59
 
   TYPE(samsim_config) :: cfg                 !< every flag / scalar that crosses the C-ABI
@@ -24,6 +25,7 @@ MODULE mo_data
   INTEGER             :: device = 0, out_col = 1
   LOGICAL             :: perturb = .FALSE.   !< per-column T2m / precipitation perturbation (SURVEY.md 8d cfg3)
   INTEGER(c_int64_t)  :: max_steps = -1
+  CHARACTER(len=1024) :: restart_in = ' ', restart_out = ' '   !< binary checkpoint files (samsim_amd/checkpoint.py format)
   INTEGER             :: i_time, i_time_out
   REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp
   INTEGER             :: N_bgc = 1
@@ -247,6 +249,7 @@ CONTAINS
     OPEN(35, file='./output/dat_psi_l.dat',       STATUS='replace', Recl=12288)
     OPEN(40, file='./output/dat_freeboard.dat',   STATUS='replace', Recl=12288)
     OPEN(41, file='./output/dat_snow.dat',        STATUS='replace', Recl=12288)
+    OPEN(51, file='./output/dat_ensemble.dat',    STATUS='replace', Recl=12288)
     OPEN(42, file='./output/dat_vital_signs.dat', STATUS='replace', Recl=12288)
     OPEN(43, file='./output/dat_grav_drain.dat',  STATUS='replace', Recl=12288)
     OPEN(45, file='./output/dat_T2m_T_top.dat',   STATUS='replace', Recl=12288)
@@ -327,12 +330,26 @@ CONTAINS
     WRITE(50, format_melt)  oscal(S_MELT_OUT1), oscal(S_MELT_OUT2), oscal(S_MELT_OUT3)
   END SUBROUTINE output
 
+  !> One row per output point with the ensemble statistics (count, then mean / min / max / std of thickness, snow thickness,
+  !! bulk salinity, freeboard, surface temperature and N_active): what stands in for "one .dat row per column" when the
+  !! run holds 10^5..10^6 columns (SURVEY.md section 8 f.1).  Column out_col keeps its own dat_*.dat files.
+  SUBROUTINE output_ensemble(h, time)
+    TYPE(c_ptr), INTENT(in) :: h
+    REAL(wp),    INTENT(in) :: time
+    INTEGER(c_int32_t) :: slots(6)
+    TYPE(samsim_stat)  :: q(6)
+    INTEGER :: j
+    slots = (/ S_THICKNESS - 1, S_THICK_SNOW - 1, S_BULK_SALIN - 1, S_FREEBOARD - 1, S_T_TOP - 1, -1 /)
+    CALL samsim_check(samsim_get_ensemble_stats(h, 6_c_int32_t, slots, q), 'samsim_get_ensemble_stats')
+    WRITE(51, '(F14.1,I10,24ES16.8)') time, q(1)%count, (q(j)%mean, q(j)%min, q(j)%max, q(j)%std, j = 1, 6)
+  END SUBROUTINE output_ensemble
+
   SUBROUTINE output_end()
     INTEGER :: u
     DO u = 30, 35
        CLOSE(u)
     END DO
-    DO u = 40, 50
+    DO u = 40, 51
        IF (u /= 44) CLOSE(u)
     END DO
   END SUBROUTINE output_end
@@ -344,6 +361,76 @@ MODULE mo_grotz
   USE mo_output
   IMPLICIT NONE
 CONTAINS
+  !> Binary checkpoint of the resident ensemble (the reference has no restart files; SURVEY.md section 8 f.1).  Same stream
+  !! format as samsim_amd/checkpoint.py: header, then chunks of columns (col0, ncols, lay, scal, n_active).
+  SUBROUTINE write_restart(h, path)
+    TYPE(c_ptr), INTENT(in) :: h
+    CHARACTER(len=*), INTENT(in) :: path
+    INTEGER(c_int64_t), PARAMETER :: chunk = 65536
+    TYPE(samsim_state_soa) :: st
+    TYPE(samsim_clock)     :: clk
+    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :)
+    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
+    INTEGER(c_int64_t) :: c0, n
+    INTEGER :: u
+    CALL samsim_check(samsim_get_clock(h, clk), 'samsim_get_clock')
+    OPEN(NEWUNIT=u, file=TRIM(path), STATUS='replace', ACCESS='stream', FORM='unformatted')
+    WRITE(u) restart_magic, ncol, INT(cfg%nlayer, c_int64_t), INT(SAMSIM_NARR, c_int64_t), INT(SAMSIM_NSCAL, c_int64_t), &
+         INT(cfg%testcase, c_int64_t), clk%time, clk%step, INT(clk%n_time_out, c_int64_t), INT(clk%time_counter, c_int64_t), &
+         clk%n_outputs, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t
+    c0 = 0
+    DO WHILE (c0 < ncol)
+       n = MIN(chunk, ncol - c0)
+       ALLOCATE(blay(n, cfg%nlayer, SAMSIM_NARR), bscal(n, SAMSIM_NSCAL), bna(n))
+       st%ncol = n; st%nlayer = cfg%nlayer; st%narr = SAMSIM_NARR
+       st%lay = c_loc(blay); st%scal = c_loc(bscal); st%n_active = c_loc(bna)
+       CALL samsim_check(samsim_get_state(h, st, c0), 'samsim_get_state')
+       WRITE(u) c0, n
+       WRITE(u) blay
+       WRITE(u) bscal
+       WRITE(u) bna
+       DEALLOCATE(blay, bscal, bna)
+       c0 = c0 + n
+    END DO
+    CLOSE(u)
+    PRINT '(A,A,A,I0)', ' restart file written: ', TRIM(path), '  step ', clk%step
+  END SUBROUTINE write_restart
+
+  SUBROUTINE read_restart(h, path)
+    TYPE(c_ptr), INTENT(in) :: h
+    CHARACTER(len=*), INTENT(in) :: path
+    TYPE(samsim_state_soa) :: st
+    TYPE(samsim_clock)     :: clk
+    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :)
+    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
+    INTEGER(c_int64_t) :: hdr(6), tail(3), pad(5), c0, n, done
+    INTEGER :: u
+    OPEN(NEWUNIT=u, file=TRIM(path), STATUS='old', ACCESS='stream', FORM='unformatted')
+    READ(u) hdr, clk%time, clk%step, tail, pad
+    IF (hdr(1) /= restart_magic .OR. hdr(2) /= ncol .OR. hdr(3) /= cfg%nlayer .OR. hdr(5) /= SAMSIM_NSCAL .OR. &
+         (hdr(4) /= SAMSIM_NARR .AND. hdr(4) /= SAMSIM_NPROG)) THEN
+       PRINT *, 'restart file does not fit this run (magic, ncol, Nlayer, narr, nscal):', hdr(1:5)
+       STOP 5
+    END IF
+    clk%n_time_out = INT(tail(1), c_int32_t); clk%time_counter = INT(tail(2), c_int32_t); clk%n_outputs = tail(3)
+    done = 0
+    DO WHILE (done < ncol)
+       READ(u) c0, n
+       ALLOCATE(blay(n, cfg%nlayer, hdr(4)), bscal(n, SAMSIM_NSCAL), bna(n))
+       READ(u) blay
+       READ(u) bscal
+       READ(u) bna
+       st%ncol = n; st%nlayer = cfg%nlayer; st%narr = INT(hdr(4), c_int32_t)
+       st%lay = c_loc(blay); st%scal = c_loc(bscal); st%n_active = c_loc(bna)
+       CALL samsim_check(samsim_set_state(h, st, c0), 'samsim_set_state')
+       DEALLOCATE(blay, bscal, bna)
+       done = done + n
+    END DO
+    CLOSE(u)
+    CALL samsim_check(samsim_set_clock(h, clk), 'samsim_set_clock')
+    PRINT '(A,A,A,I0)', ' restarted from ', TRIM(path), '  step ', clk%step
+  END SUBROUTINE read_restart
+
   !> grotz, mo_grotz.f90:83-877: initialisation, forcing read-in, time loop, final output.  The loop body is one
   !! samsim_step call per output interval; `output` is fed from the snapshot the kernel takes at the reference's output point.
   SUBROUTINE grotz(testcase, description, nml_unit)
@@ -379,6 +466,7 @@ CONTAINS
     st%ncol = ncol; st%nlayer = cfg%nlayer; st%narr = SAMSIM_NARR
     st%lay = c_loc(lay); st%scal = c_loc(scal); st%n_active = c_loc(n_active)
     CALL samsim_check(samsim_set_state(h, st, 0_c_int64_t), 'samsim_set_state')
+    IF (LEN_TRIM(restart_in) > 0) CALL read_restart(h, restart_in)
     CALL samsim_check(samsim_set_output_window(h, INT(out_col - 1, c_int64_t), 1_c_int64_t), 'samsim_set_output_window')
     ALLOCATE(olay(1, cfg%nlayer, SAMSIM_NARR), oscal(1, SAMSIM_NSCAL), ona(1))
     o%ncols = 1; o%nlayer = cfg%nlayer; o%reserved = 0
@@ -386,7 +474,8 @@ CONTAINS
 
     total = i_time
     IF (max_steps >= 0) total = MIN(total, max_steps)
-    done = 0
+    CALL samsim_check(samsim_get_clock(h, clk), 'samsim_get_clock')
+    done = clk%step            ! > 0 after a restart: the run continues to the same end
     CALL SYSTEM_CLOCK(count0, rate)
     DO WHILE (done < total)
        n = MIN(samsim_steps_to_output(h), total - done)
@@ -395,6 +484,7 @@ CONTAINS
        IF (samsim_steps_to_output(h) == cfg%i_time_out + 1 .OR. done == 1) THEN   ! an output point was just passed
           CALL samsim_check(samsim_get_output(h, o), 'samsim_get_output')
           CALL output(cfg%nlayer, olay(1, :, :), oscal(1, :))
+          CALL output_ensemble(h, o%time)
           time = o%time
           thick1 = olay(1, 1, A_THICK)
           ! console progress line, mo_grotz.f90:371-381
@@ -425,6 +515,7 @@ CONTAINS
     WRITE(*, '(A,I0,A,I0,A,F9.3,A,ES10.3,A)') ' MI355X: ', ncol, ' columns x ', clk%step, ' steps in ', &
          REAL(count1 - count0, wp)/REAL(rate, wp), ' s  (', REAL(colsteps, wp)/(REAL(count1 - count0, wp)/REAL(rate, wp)), &
          ' column-timesteps/s)'
+    IF (LEN_TRIM(restart_out) > 0) CALL write_restart(h, restart_out)
     CALL output_end()
     CALL samsim_destroy(h)
     CALL sub_deallocate()
@@ -439,7 +530,7 @@ PROGRAM SAMSIM
   INTEGER         :: testcase, ios, nml_unit
   CHARACTER*12000 :: description
   LOGICAL         :: have_nml
-  NAMELIST /samsim_run/ testcase, ncol, device, out_col, perturb, description, max_steps
+  NAMELIST /samsim_run/ testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out
 
   testcase    = 1
   description = 'MI355X-native batched column solver'

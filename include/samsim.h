@@ -167,6 +167,17 @@ int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t 
 /* sum over columns of N_active accumulated over all steps taken (layer-cell updates) */
 int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
 
+/* Ensemble statistics (what replaces "one column per .dat row", mo_output.f90:129-144, when the
+ * run holds 10^5..10^6 columns): for each requested per-column scalar (enum samsim_scalar, or SAMSIM_STAT_N_ACTIVE) the
+ * number of columns that have not failed, their mean, minimum, maximum and population standard deviation, reduced on the
+ * device.  The vital signs and the freeboard hold the values of the last output point (mo_grotz.f90:192-223, 340-347). */
+#define SAMSIM_STAT_N_ACTIVE (-1)
+typedef struct samsim_stat {
+  int64_t count;
+  double  mean, min, max, std;
+} samsim_stat;
+int samsim_get_ensemble_stats(samsim_handle *h, int32_t nslots, const int32_t *slots, samsim_stat *out);
+
 void samsim_destroy(samsim_handle *h);
 const char *samsim_strerror(int code);
 int samsim_abi_version(void);

@@ -1662,6 +1662,37 @@ int oracle_step(oracle_handle *h, int64_t nsteps) {
   return SAMSIM_OK;
 }
 
+/* mirror of samsim_get_ensemble_stats (include/samsim.h): plain two-pass statistics over the columns without a STOP code */
+int oracle_get_ensemble_stats(oracle_handle *h, int32_t nslots, const int32_t *slots, samsim_stat *out) {
+  if (!h || nslots < 0 || (nslots > 0 && (!slots || !out))) return SAMSIM_ERR_ARG;
+  for (int s = 0; s < nslots; s++) {
+    int slot = slots[s];
+    if (slot != SAMSIM_STAT_N_ACTIVE && (slot < 0 || slot >= SAMSIM_NSCAL)) return SAMSIM_ERR_ARG;
+    samsim_stat st = {0, 0.0, 1.0e300, -1.0e300, 0.0};
+    double sum = 0.0, ssq = 0.0;
+    for (int64_t i = 0; i < h->ncol; i++) {
+      column *c = &h->cols[i];
+      if (c->status) continue;
+      double v = (slot == SAMSIM_STAT_N_ACTIVE) ? (double)c->N_active : *scal_slot(c, slot);
+      sum += v; st.count++;
+      if (v < st.min) st.min = v;
+      if (v > st.max) st.max = v;
+    }
+    if (st.count > 0) {
+      st.mean = sum / (double)st.count;
+      for (int64_t i = 0; i < h->ncol; i++) {
+        column *c = &h->cols[i];
+        if (c->status) continue;
+        double v = (slot == SAMSIM_STAT_N_ACTIVE) ? (double)c->N_active : *scal_slot(c, slot);
+        ssq += (v - st.mean) * (v - st.mean);
+      }
+      st.std = sqrt(ssq / (double)st.count);
+    } else { st.min = st.max = 0.0; }
+    out[s] = st;
+  }
+  return SAMSIM_OK;
+}
+
 int oracle_step_part_b(oracle_handle *h) {
   if (!h) return SAMSIM_ERR_ARG;
   for (int64_t i = 0; i < h->ncol; i++) {

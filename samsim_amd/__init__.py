@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as _C
 import os as _os
 
-from . import capi, testcases  # noqa: F401
+from . import capi, checkpoint, testcases  # noqa: F401
 from .capi import Config, State, Output, Solver, SamsimError, HIP_LIB_PATH  # noqa: F401
 
 _lib = None

@@ -48,6 +48,11 @@ class Clock(C.Structure):
                 ("time_counter", C.c_int32), ("n_outputs", C.c_int64)]
 
 
+class Stat(C.Structure):
+    """samsim_stat"""
+    _fields_ = [("count", C.c_int64), ("mean", C.c_double), ("min", C.c_double), ("max", C.c_double), ("std", C.c_double)]
+
+
 class OutputSoA(C.Structure):
     _fields_ = [("ncols", C.c_int64), ("nlayer", C.c_int32), ("reserved", C.c_int32),
                 ("lay", C.POINTER(C.c_double)), ("scal", C.POINTER(C.c_double)),
@@ -185,6 +190,7 @@ class Solver:
             "step": [vp, i64], "set_output_window": [vp, i64, i64], "get_output": [vp, C.POINTER(OutputSoA)],
             "get_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
             "get_work": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+            "get_ensemble_stats": [vp, i32, C.POINTER(C.c_int32), C.POINTER(Stat)],
         }
         for n, a in sig.items():
             f = self._f(n)
@@ -273,6 +279,14 @@ class Solver:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self._f("get_work")(self._h, C.byref(a), C.byref(b)), "get_work")
         return a.value, b.value
+
+    def ensemble_stats(self, names):
+        """{name: Stat} over the columns without a STOP code; names from SCALARS or "N_active" (samsim_get_ensemble_stats)"""
+        names = list(names)
+        slots = (C.c_int32 * len(names))(*[-1 if n == "N_active" else S[n] for n in names])
+        out = (Stat * len(names))()
+        self._chk(self._f("get_ensemble_stats")(self._h, len(names), slots, out), "get_ensemble_stats")
+        return {n: out[i] for i, n in enumerate(names)}
 
     def run_to_output(self) -> Output:
         """advance to (and through) the next output point of mo_grotz.f90:340 and return its snapshot"""

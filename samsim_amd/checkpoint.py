@@ -1,0 +1,73 @@
+"""Binary checkpoint / restart files for a resident ensemble (the reference has none: a
+run there always starts from `init(testcase)`).
+
+The file is a little-endian stream that the Fortran host reads and writes as well (host/host_driver.f90, ACCESS='stream'):
+
+    header   int64 magic "SAMCHK01", ncol, nlayer, narr, nscal, testcase,
+             float64 time, int64 step, n_time_out, time_counter, n_outputs, int64 reserved[5]
+    chunks   int64 col0, ncols, then lay[narr][nlayer][ncols], scal[nscal][ncols] (float64), n_active[ncols] (int32)
+             ... until ncol columns are covered
+
+It holds what `samsim_get_state` / `samsim_get_clock` return: with all 15 layer arrays (`narr = NARR`, the default) a
+restart continues bit for bit; with the 4 prognostic arrays (`narr = NPROG`) the diagnostics are rebuilt by the first
+sweep of the next step and only the paths that read last step's temperature (rain into open water) see a difference.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .capi import NARR, NPROG, NSCAL, Solver, State
+
+MAGIC = int.from_bytes(b"SAMCHK01", "little")
+_HDR = struct.Struct("<6q d 4q 5q")
+
+
+def save(solver: Solver, path: str, narr: int = NARR, chunk: int = 65536) -> None:
+    """stream the state of `solver` to `path`, `chunk` columns at a time"""
+    assert narr in (NARR, NPROG)
+    k = solver.get_clock()
+    with open(path, "wb") as f:
+        f.write(_HDR.pack(MAGIC, solver.ncol, solver.nlayer, narr, NSCAL, int(solver.cfg.testcase), float(k.time),
+                          int(k.step), int(k.n_time_out), int(k.time_counter), int(k.n_outputs), 0, 0, 0, 0, 0))
+        c0 = 0
+        while c0 < solver.ncol:
+            n = min(chunk, solver.ncol - c0)
+            st = solver.get_state(col0=c0, ncols=n, narr=narr)
+            f.write(struct.pack("<2q", c0, n))
+            f.write(np.ascontiguousarray(st.lay, dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(st.scal, dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(st.n_active, dtype="<i4").tobytes())
+            c0 += n
+
+
+def read_header(path: str) -> dict:
+    with open(path, "rb") as f:
+        v = _HDR.unpack(f.read(_HDR.size))
+    if v[0] != MAGIC:
+        raise ValueError(f"{path}: not a SAMSIM checkpoint")
+    return dict(ncol=v[1], nlayer=v[2], narr=v[3], nscal=v[4], testcase=v[5], time=v[6], step=v[7], n_time_out=v[8],
+                time_counter=v[9], n_outputs=v[10])
+
+
+def load(solver: Solver, path: str) -> dict:
+    """upload the state and the clock stored in `path` into `solver` (same ncol and nlayer); returns the header"""
+    h = read_header(path)
+    if (h["ncol"], h["nlayer"]) != (solver.ncol, solver.nlayer) or h["nscal"] != NSCAL or h["narr"] not in (NARR, NPROG):
+        raise ValueError(f"{path}: holds {h['ncol']} columns x {h['nlayer']} layers x {h['nscal']} scalars, "
+                         f"the solver {solver.ncol} x {solver.nlayer} x {NSCAL}")
+    with open(path, "rb") as f:
+        f.seek(_HDR.size)
+        done = 0
+        while done < h["ncol"]:
+            c0, n = struct.unpack("<2q", f.read(16))
+            lay = np.frombuffer(f.read(8 * h["narr"] * h["nlayer"] * n), dtype="<f8").reshape(h["narr"], h["nlayer"], n)
+            scal = np.frombuffer(f.read(8 * NSCAL * n), dtype="<f8").reshape(NSCAL, n)
+            na = np.frombuffer(f.read(4 * n), dtype="<i4")
+            solver.set_state(State(np.ascontiguousarray(lay, dtype=np.float64), np.ascontiguousarray(scal, dtype=np.float64),
+                                   np.ascontiguousarray(na, dtype=np.int32)), c0)
+            done += n
+    solver.set_clock(time=h["time"], step=h["step"], n_time_out=h["n_time_out"], time_counter=h["time_counter"],
+                     n_outputs=h["n_outputs"])
+    return h

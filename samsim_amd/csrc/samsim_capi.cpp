@@ -47,6 +47,7 @@ struct samsim_handle {
   long long *err_step = nullptr, *work = nullptr;
   double *spec = nullptr;      // hand-over block of the up sweep, [DEV_NSPEC][ncol]
   int32_t *flags = nullptr;    // COLF_* per column
+  void *d_stat = nullptr;      // block partials of samsim_get_ensemble_stats
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
   int32_t flen = 0;
   double *out_lay = nullptr, *out_scal = nullptr;
@@ -88,6 +89,46 @@ int validate(const samsim_config &c) {
 
 template <typename T>
 hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+// ---- ensemble statistics: two passes (mean / min / max, then the squared deviations) over one [ncol] row, columns with a
+// STOP code skipped; fixed grid + tree reduction, so the result does not depend on scheduling
+constexpr int kStatBlock = 256, kStatGrid = 512;
+struct StatPartial { double sum, mn, mx, ssq; long long n; };
+
+template <bool PASS2>
+__global__ void __launch_bounds__(kStatBlock) stat_kernel(const double *__restrict__ row, const int32_t *__restrict__ irow,
+                                                          const int32_t *__restrict__ status, long long n, double mean,
+                                                          StatPartial *__restrict__ part) {
+  __shared__ double s_sum[kStatBlock], s_mn[kStatBlock], s_mx[kStatBlock];
+  __shared__ long long s_n[kStatBlock];
+  double sum = 0.0, mn = 1.0e300, mx = -1.0e300;
+  long long cnt = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (status[i]) continue;
+    const double v = row ? row[i] : (double)irow[i];
+    if (PASS2) {
+      sum += (v - mean) * (v - mean);
+    } else {
+      sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; ++cnt;
+    }
+  }
+  const int t = threadIdx.x;
+  s_sum[t] = sum; s_mn[t] = mn; s_mx[t] = mx; s_n[t] = cnt;
+  __syncthreads();
+  for (int w = kStatBlock / 2; w > 0; w >>= 1) {
+    if (t < w) {
+      s_sum[t] += s_sum[t + w];
+      s_mn[t] = s_mn[t + w] < s_mn[t] ? s_mn[t + w] : s_mn[t];
+      s_mx[t] = s_mx[t + w] > s_mx[t] ? s_mx[t + w] : s_mx[t];
+      s_n[t] += s_n[t + w];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (PASS2) part[blockIdx.x].ssq = s_sum[0];
+    else { part[blockIdx.x].sum = s_sum[0]; part[blockIdx.x].mn = s_mn[0]; part[blockIdx.x].mx = s_mx[0]; part[blockIdx.x].n = s_n[0]; }
+  }
+}
 
 // fill a [rows][ncol] device block with one value per row-set
 __global__ void fill_rows(double *dst, size_t n, double v) {
@@ -261,7 +302,7 @@ void samsim_destroy(samsim_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
-  (void)hipFree(h->spec); (void)hipFree(h->flags);
+  (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat);
   (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
   (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
   (void)hipFree(h->d_params);
@@ -455,6 +496,46 @@ int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *colu
   for (size_t i = 0; i < nc; ++i) tot += w[i];
   if (layer_cell_updates) *layer_cell_updates = tot;
   if (column_steps) *column_steps = (int64_t)h->clk.step * (int64_t)h->ncol;
+  return SAMSIM_OK;
+}
+
+int samsim_get_ensemble_stats(samsim_handle *h, int32_t nslots, const int32_t *slots, samsim_stat *out) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (nslots < 0 || (nslots > 0 && (!slots || !out))) return SAMSIM_ERR_ARG;
+  for (int i = 0; i < nslots; ++i)
+    if (slots[i] != SAMSIM_STAT_N_ACTIVE && (slots[i] < 0 || slots[i] >= SAMSIM_NSCAL)) return SAMSIM_ERR_ARG;
+  if (!h->d_stat) HIPCHK(hipMalloc(&h->d_stat, sizeof(StatPartial) * kStatGrid));
+  StatPartial *d_part = (StatPartial *)h->d_stat;
+  std::vector<StatPartial> part(kStatGrid);
+  const long long nc = h->ncol;
+  for (int i = 0; i < nslots; ++i) {
+    const double *row = (slots[i] == SAMSIM_STAT_N_ACTIVE) ? nullptr : h->scal + (size_t)slots[i] * (size_t)nc;
+    hipLaunchKernelGGL(stat_kernel<false>, dim3(kStatGrid), dim3(kStatBlock), 0, h->stream, row, h->n_active, h->status, nc, 0.0,
+                       d_part);
+    HIPCHK(hipMemcpyAsync(part.data(), d_part, sizeof(StatPartial) * kStatGrid, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    samsim_stat st{0, 0.0, 1.0e300, -1.0e300, 0.0};
+    double sum = 0.0;
+    for (const StatPartial &q : part) {
+      st.count += q.n; sum += q.sum;
+      st.min = q.mn < st.min ? q.mn : st.min;
+      st.max = q.mx > st.max ? q.mx : st.max;
+    }
+    if (st.count > 0) {
+      st.mean = sum / (double)st.count;
+      hipLaunchKernelGGL(stat_kernel<true>, dim3(kStatGrid), dim3(kStatBlock), 0, h->stream, row, h->n_active, h->status, nc,
+                         st.mean, d_part);
+      HIPCHK(hipMemcpyAsync(part.data(), d_part, sizeof(StatPartial) * kStatGrid, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      double ssq = 0.0;
+      for (const StatPartial &q : part) ssq += q.ssq;
+      st.std = sqrt(ssq / (double)st.count);
+    } else {
+      st.min = st.max = 0.0;
+    }
+    out[i] = st;
+  }
   return SAMSIM_OK;
 }
 

@@ -2,10 +2,12 @@
 import re
 
 import numpy as np
+import pytest
 
 from samsim_amd import testcases as tcs
 from samsim_amd.capi import State, NARR, NSCAL
 from tests.helpers import golden
+from tests.oracle_lib import oracle_solver
 
 
 def test_testcase1_settings_match_reference_dat_settings():
@@ -52,3 +54,59 @@ def test_state_replicate_and_window():
     assert r.lay.shape[2] == 5 and (r.lay == st.lay[:, :, :1]).all()
     w = r.window(2, 2)
     assert w.ncol == 2 and w.lay.flags.c_contiguous
+
+
+def test_checkpoint_file_roundtrip_and_bitwise_continuation(tmp_path):
+    """samsim_amd.checkpoint driven through the checker library: a run interrupted by save -> new handle
+    -> load continues bit for bit, in column chunks that do not divide the ensemble"""
+    from samsim_amd import checkpoint
+    from tests.helpers import sheba_forcing
+    ncol = 10
+    cfg, st = tcs.testcase4(ncol)
+    dT, ps = tcs.ensemble_perturbation(ncol)
+
+    def fresh():
+        o = oracle_solver(cfg, ncol)
+        o.set_forcing(*sheba_forcing(), dT, ps)
+        return o
+    a = fresh()
+    a.set_state(st)
+    a.set_clock()
+    a.step(9000)                       # past the first output point and the first ice layers
+    path = str(tmp_path / "restart.chk")
+    checkpoint.save(a, path, chunk=4)
+    h = checkpoint.read_header(path)
+    assert (h["ncol"], h["nlayer"], h["step"], h["testcase"]) == (ncol, cfg.nlayer, 9000, 4)
+    b = fresh()
+    checkpoint.load(b, path)
+    a.step(3000)
+    b.step(3000)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa.lay, sb.lay) and np.array_equal(sa.scal, sb.scal) and np.array_equal(sa.n_active, sb.n_active)
+    ka, kb = a.get_clock(), b.get_clock()
+    assert (ka.time, ka.step, ka.n_time_out, ka.time_counter) == (kb.time, kb.step, kb.n_time_out, kb.time_counter)
+    with pytest.raises(ValueError):
+        checkpoint.load(oracle_solver(cfg, ncol + 1), path)
+
+
+def test_ensemble_statistics_of_the_checker():
+    """samsim_get_ensemble_stats semantics (count / mean / min / max / population std over the columns without a STOP
+    code) on the checker library against numpy"""
+    from tests.helpers import sheba_forcing
+    ncol = 24
+    cfg, st = tcs.testcase4(ncol)
+    o = oracle_solver(cfg, ncol)
+    o.set_forcing(*sheba_forcing(), *tcs.ensemble_perturbation(ncol))
+    o.set_state(st)
+    o.set_clock()
+    o.run_to_output()
+    o.step(8641)                       # second output point: vital signs of an ice-covered ensemble
+    s = o.get_state()
+    stats = o.ensemble_stats(["thickness", "thick_snow", "T2m", "N_active"])
+    for n in ("thickness", "thick_snow", "T2m"):
+        v = s.sc(n)
+        q = stats[n]
+        assert q.count == ncol and q.min == v.min() and q.max == v.max()
+        assert abs(q.mean - v.mean()) <= 1e-13 * max(1.0, abs(v.mean())) and abs(q.std - v.std()) <= 1e-12 * max(1.0, v.std())
+    assert stats["N_active"].max == s.n_active.max() and stats["N_active"].mean == pytest.approx(s.n_active.mean())
+    assert stats["T2m"].std > 0.5
