@@ -17,8 +17,9 @@ MODULE mo_samsim_capi
                         S_GRAV_SALT = 17, S_GRAV_TEMP = 18, S_MELT_OUT1 = 19, S_MELT_OUT2 = 20, S_MELT_OUT3 = 21, &
                         S_MELT_ERR = 22, S_FREEBOARD = 23, S_T_FREEZE = 24, S_ALBEDO = 25, S_FL_SW = 26, S_FL_LW = 27, &
                         S_MELT_THICK_SNOW = 28, S_FL_Q_SNOW = 29, S_ENERGY_STORED = 30, S_FRESHWATER = 31, &
-                        S_TOTAL_RESIST = 32, S_THICKNESS = 33, S_BULK_SALIN = 34, S_FL_REST = 35, S_DT2M = 36, S_PRECIP_SCALE = 37, &
-                        SAMSIM_NSCAL = 37
+                        S_TOTAL_RESIST = 32, S_THICKNESS = 33, S_BULK_SALIN = 34, S_FL_REST = 35, S_S_BU_BOTTOM = 36, S_DT2M = 37, &
+                        S_PRECIP_SCALE = 38, &
+                        SAMSIM_NSCAL = 38
 
   TYPE, BIND(C) :: samsim_config
      INTEGER(c_int32_t) :: struct_size, testcase, nlayer, n_top, n_middle, n_bottom
@@ -27,6 +28,7 @@ MODULE mo_samsim_capi
                            tank_flag, albedo_flag, lab_snow_flag, freeboard_snow_flag, snow_flush_flag, snow_precip_flag, &
                            bgc_flag, i_time_out
      REAL(c_double)     :: dt, thick_0, thick_min, T_bottom, S_bu_bottom, k_snow_flush, max_flux_plate, time_out, time_total
+     REAL(c_double)     :: alpha_flux_instable, alpha_flux_stable, m_total, S_total
   END TYPE samsim_config
 
   TYPE, BIND(C) :: samsim_state_soa

@@ -27,7 +27,7 @@ MODULE mo_data
   INTEGER(c_int64_t)  :: max_steps = -1
   CHARACTER(len=1024) :: restart_in = ' ', restart_out = ' '   !< binary checkpoint files (samsim_amd/checkpoint.py format)
   INTEGER             :: i_time, i_time_out
-  REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp
+  REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp, T2m = 0._wp, tank_depth = 0._wp
   INTEGER             :: N_bgc = 1
   ! host copies: SoA blocks, column fastest (= C layout [array][layer][column])
   REAL(c_double), ALLOCATABLE, TARGET    :: lay(:, :, :), scal(:, :)
@@ -67,7 +67,7 @@ CONTAINS
     NAMELIST /samsim_flags/ Nlayer, N_top, N_bottom, boundflux_flag, atmoflux_flag, albedo_flag, grav_flag, flush_flag, &
          flood_flag, grav_heat_flag, flush_heat_flag, harmonic_flag, salt_flag, turb_flag, bottom_flag, precip_flag, &
          freeboard_snow_flag, snow_flush_flag, dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush, &
-         fl_q_bottom, T_top
+         fl_q_bottom, T_top, T2m, tank_depth
 
     CALL default_flags()
     cfg%testcase = testcase
@@ -83,6 +83,26 @@ CONTAINS
        cfg%snow_flush_flag = 1; cfg%flush_heat_flag = 2; cfg%snow_precip_flag = 1
        cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
        cfg%thick_0 = 0.01_wp; cfg%time_out = 86400._wp; cfg%time_total = cfg%time_out*365._wp*4.5_wp; cfg%dt = 10._wp
+    ELSE IF (testcase == 2 .OR. testcase == 6 .OR. testcase == 9) THEN
+       ! tank experiments, mo_init.f90:948-1003, 1278-1330, 1684-1740 (bgc off)
+       cfg%tank_flag = 2; cfg%boundflux_flag = 3; cfg%grav_heat_flag = 1
+       cfg%alpha_flux_instable = 22.0_wp
+       IF (testcase == 2) THEN
+          fl_q_bottom = 10._wp; cfg%alpha_flux_stable = 15._wp; tank_depth = 1._wp
+          cfg%nlayer = 100; cfg%n_bottom = 10; cfg%n_top = 3
+          T2m = -20._wp; T_top = -18._wp; cfg%T_bottom = 0.0_wp; cfg%S_bu_bottom = 31.2_wp
+          cfg%thick_0 = 0.01_wp; cfg%time_out = 3600._wp*6._wp; cfg%time_total = cfg%time_out*4._wp*30._wp; cfg%dt = 30._wp
+       ELSE IF (testcase == 6) THEN
+          fl_q_bottom = 35._wp; cfg%alpha_flux_stable = 11._wp; tank_depth = 0.159_wp
+          cfg%nlayer = 40; cfg%n_bottom = 3; cfg%n_top = 3
+          T2m = -18._wp; T_top = -18._wp; cfg%T_bottom = 0.0_wp; cfg%S_bu_bottom = 31.2_wp
+          cfg%thick_0 = 0.0025_wp; cfg%time_out = 1800._wp/2._wp; cfg%time_total = cfg%time_out*39._wp*2._wp*2._wp; cfg%dt = 0.5
+       ELSE
+          fl_q_bottom = 10._wp; cfg%alpha_flux_stable = 15._wp; tank_depth = 0.8_wp
+          cfg%nlayer = 100; cfg%n_bottom = 10; cfg%n_top = 3
+          T2m = -15._wp; T_top = -10._wp; cfg%T_bottom = -0.07_wp; cfg%S_bu_bottom = 34.6_wp
+          cfg%thick_0 = 0.005_wp; cfg%time_out = 3600._wp*2._wp; cfg%time_total = cfg%time_out*12._wp*6._wp; cfg%dt = 10._wp
+       END IF
     ELSE IF (testcase == 3) THEN
        cfg%nlayer = 20; cfg%n_top = 5; cfg%n_bottom = 5
        cfg%atmoflux_flag = 1; cfg%precip_flag = 0; cfg%boundflux_flag = 2
@@ -140,6 +160,10 @@ CONTAINS
        STOP 666
     END IF
     cfg%thick_min = cfg%thick_0/2._wp
+    IF (cfg%tank_flag == 2) THEN            ! water and salt in the tank, mo_init.f90:996-997
+       cfg%m_total = rho_l*tank_depth
+       cfg%S_total = rho_l*cfg%S_bu_bottom*tank_depth
+    END IF
     i_time = INT(cfg%time_total/cfg%dt)
     i_time_out = INT(cfg%time_out/cfg%dt)
     cfg%i_time_out = i_time_out
@@ -154,6 +178,8 @@ CONTAINS
     scal(:, S_FL_Q_BOTTOM) = fl_q_bottom
     scal(:, S_FL_SW) = fl_sw
     scal(:, S_FL_REST) = fl_rest
+    scal(:, S_T2M) = T2m
+    scal(:, S_S_BU_BOTTOM) = cfg%S_bu_bottom
     IF (testcase == 5) THEN
        ! a slab: every layer active, thick = thick_0, 5 g/kg, -90 c_l J/kg (mo_init.f90:1217,1270-1273)
        n_active = cfg%nlayer
@@ -169,6 +195,8 @@ CONTAINS
        lay(:, 1, A_S_ABS) = cfg%S_bu_bottom*lay(:, 1, A_M)
        IF (testcase == 1) THEN
           lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom*c_l
+       ELSE IF (cfg%tank_flag == 2) THEN
+          lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom          ! as written in mo_init.f90:1002
        ELSE
           lay(:, 1, A_H_ABS) = 0._wp
        END IF

@@ -28,15 +28,16 @@
 extern "C" {
 #endif
 
-#define SAMSIM_ABI_VERSION 1
+#define SAMSIM_ABI_VERSION 2
 #define SAMSIM_MAX_NLAYER 1024
 
 /* -------- configuration: every flag of mo_data.f90:136-155 plus the scalars mo_init sets -------- */
 typedef struct samsim_config {
   int32_t struct_size;          /* = sizeof(samsim_config); ABI check                                */
   int32_t testcase;             /* selects the time-dependent forcing of mo_grotz.f90:503-565:
-                                   1 sub_test1 (T_top toggles), 3 sub_test3 (snow fall), 4/7 sub_test4
-                                   (fl_q_bottom), 5 (S_abs reset at step 2), 0 none                   */
+                                   1 sub_test1 (T_top toggles), 2/6/9 sub_test2/6/9 (T2m schedule of the tank
+                                   experiments), 3 sub_test3 (snow fall), 4/7 sub_test4 (fl_q_bottom),
+                                   5 (S_abs reset at step 2), 0 none                                  */
   int32_t nlayer, n_top, n_middle, n_bottom;          /* mo_data.f90:62-65                           */
   int32_t atmoflux_flag;        /* 1 Notz climatology, 2 forcing tables, 3 fixed fl_sw / fl_rest     */
   int32_t grav_flag;            /* 1 none, 2 Rayleigh-number gravity drainage, 3 simple              */
@@ -45,16 +46,16 @@ typedef struct samsim_config {
   int32_t flush_heat_flag;      /* 1, 2                                                              */
   int32_t turb_flag;            /* 1, 2                                                              */
   int32_t salt_flag;            /* 1 sea salt, 2 NaCl                                                */
-  int32_t boundflux_flag;       /* 1 cooling plate, 2 radiative balance (3 not supported)            */
+  int32_t boundflux_flag;       /* 1 cooling plate, 2 radiative balance, 3 lab air temperature T2m   */
   int32_t flush_flag;           /* 1 none, 4 melt water removed, 5 flush3 (6 not supported)          */
   int32_t flood_flag;           /* 1 none, 2 flood, 3 flood_simple                                   */
   int32_t bottom_flag;          /* 1, 2                                                              */
   int32_t debug_flag;           /* 1 (ignored)                                                       */
   int32_t precip_flag;          /* 0, 1                                                              */
   int32_t harmonic_flag;        /* 1, 2                                                              */
-  int32_t tank_flag;            /* 1 (2 not supported)                                               */
+  int32_t tank_flag;            /* 1 ocean of fixed salinity, 2 tank: S_bu_bottom from the salt budget */
   int32_t albedo_flag;          /* 1, 2                                                              */
-  int32_t lab_snow_flag;        /* 0 (unused outside boundflux_flag 3)                               */
+  int32_t lab_snow_flag;        /* 0 (1, snow in the lab with boundflux_flag 3, not supported)       */
   int32_t freeboard_snow_flag;  /* 0, 1                                                              */
   int32_t snow_flush_flag;      /* 0, 1                                                              */
   int32_t snow_precip_flag;     /* (echo only)                                                       */
@@ -64,6 +65,8 @@ typedef struct samsim_config {
   double  T_bottom, S_bu_bottom;
   double  k_snow_flush, max_flux_plate;      /* mo_parameters.f90:107,110                            */
   double  time_out, time_total;              /* echo / grav_* normalisation mo_grotz.f90:355-356     */
+  double  alpha_flux_instable, alpha_flux_stable;   /* boundflux_flag 3, mo_heat_fluxes.f90:208-214   */
+  double  m_total, S_total;                  /* tank_flag 2: water and salt in the tank, mo_init.f90:996-997 */
 } samsim_config;
 
 /* -------- per-column scalar slots (state + accumulators + output-only), s[idx*ncol + c] -------- */
@@ -79,6 +82,8 @@ enum samsim_scalar {
   SAMSIM_S_ENERGY_STORED, SAMSIM_S_FRESHWATER, SAMSIM_S_TOTAL_RESIST,     /* vital signs             */
   SAMSIM_S_THICKNESS, SAMSIM_S_BULK_SALIN,
   SAMSIM_S_FL_REST,             /* bundled long-wave + turbulent flux (constant for atmoflux_flag 3) */
+  SAMSIM_S_S_BU_BOTTOM,         /* salinity of the water below: evolves with tank_flag 2 (mo_grotz.f90:573-575);
+                                   with tank_flag 1 an echo of cfg.S_bu_bottom that set_state ignores      */
   SAMSIM_S_DT2M, SAMSIM_S_PRECIP_SCALE,                                   /* ensemble perturbation   */
   SAMSIM_NSCAL
 };

@@ -55,6 +55,7 @@ typedef struct column {
   double grav_drain, grav_salt, grav_temp;
   double energy_stored, freshwater, total_resist, thickness, bulk_salin;
   double dT2m, precip_scale;
+  double S_bu_bottom;            /* salinity of the water below the ice: cfg value, or the tank budget (tank_flag 2) */
   /* clock */
   double time;
   int64_t step;                  /* completed steps; i = step+1 */
@@ -272,6 +273,22 @@ static void sub_notzflux(double time, double *fl_sw, double *fl_rest) {
   if (day < 60.0 || day > 300.0) *fl_sw = 0.0;
 }
 
+/* sub_test2, sub_test9, sub_test6: air-temperature schedules of the tank experiments, mo_testcase_specifics.f90:99-136,211-232 */
+static void sub_test2(double time, double *T2m) {
+  if (time > 86400.0 * 25.0) *T2m = 15.0;
+  else if (time > 86400.0 * 15.0) *T2m = 1.0;
+}
+static void sub_test9(double time, double *T2m) {
+  if (time < 19.75 * 3600.0) *T2m = 0.0;
+  else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) *T2m = -15.0;
+  else *T2m = 1.0;
+}
+static void sub_test6(double time, double *T2m) {
+  static const double t[8] = {1714.0, 1676.0, 1525.0, 1483.0, 1385.0, 1349.0, 1160.0, 1100.0};
+  static const double v[8] = {-19.0, -5.0, -18.0, -5.0, -18.0, -5.0, -18.0, -5.0};
+  for (int i = 0; i < 8; i++) if (time > t[i] * 60.0) { *T2m = v[i]; return; }
+}
+
 /* sub_turb_flux, mo_functions.f90:347-363 */
 static void sub_turb_flux(double T_bottom, double S_bu_bottom, double T, double *S_abs, double m, double dt) {
   double turb = Turb_A * exp(Turb_B * (-oracle_func_density(T_bottom, S_bu_bottom) + oracle_func_density(T, *S_abs / m))) * dt;
@@ -330,8 +347,8 @@ static void mass_transfer(column *c, const double *fl_m) {
   (void)N;
   for (k = 1; k <= Na; k++) { TT[k] = c->T[k]; SS_bu[k] = c->S_bu[k]; SS_abs[k] = S_abs[k]; }
   TT[Na + 1] = c->cfg->T_bottom;
-  SS_bu[Na + 1] = c->cfg->S_bu_bottom;
-  SS_abs[Na + 1] = c->cfg->S_bu_bottom * 2000.0;
+  SS_bu[Na + 1] = c->S_bu_bottom;
+  SS_abs[Na + 1] = c->S_bu_bottom * 2000.0;
   for (k = 1; k <= Na; k++) {
     if (fl_m[k + 1] > 0.0) {
       H_abs[k] = H_abs[k] + fl_m[k + 1] * TT[k + 1] * c_l;
@@ -737,7 +754,7 @@ static void flood(column *c) {
   if (freeboard + shift_ice < neg_free) {
     shift = neg_free - (freeboard + shift_ice);
     flood_brine = shift * (psi_g_snow) * rho_l;
-    S_abs[Na] = S_abs[Na] + (g->S_bu_bottom - S_bu[Na]) * flood_brine;
+    S_abs[Na] = S_abs[Na] + (c->S_bu_bottom - S_bu[Na]) * flood_brine;
     H_abs[Na] = H_abs[Na] + (g->T_bottom - T[Na]) * c_l * flood_brine;
     S_abs[1] = S_abs[1] + S_bu[Na] * flood_brine;
     H_abs[1] = H_abs[1] + T[Na] * c_l * flood_brine;
@@ -758,7 +775,7 @@ static void flood_simple(column *c) {
   double flood_brine = -shift * c->psi_g_snow * rho_l;
   double *S_abs = c->S_abs, *H_abs = c->H_abs, *m = c->m, *thick = c->thick;
   thick[1] = thick[1] - shift;
-  S_abs[1] = S_abs[1] + g->S_bu_bottom * flood_brine;
+  S_abs[1] = S_abs[1] + c->S_bu_bottom * flood_brine;
   H_abs[1] = H_abs[1] - shift / c->thick_snow * c->H_abs_snow;
   H_abs[1] = H_abs[1] + g->T_bottom * c_l * flood_brine;
   m[1] = m[1] - shift / c->thick_snow * c->m_snow;
@@ -959,7 +976,7 @@ static void bottom_growth(column *c) {
   for (k = N - N_bottom + 1; k <= N - 1; k++) { H_abs[k] = H_abs[k + 1]; S_abs[k] = S_abs[k + 1]; m[k] = m[k + 1]; }
   m[N] = thick[N] * rho_l;
   H_abs[N] = m[N] * g->T_bottom * c_l;
-  S_abs[N] = m[N] * g->S_bu_bottom;
+  S_abs[N] = m[N] * c->S_bu_bottom;
 }
 
 /* bottom_growth_simple, mo_layer_dynamics.f90:537-560 */
@@ -970,7 +987,7 @@ static void bottom_growth_simple(column *c) {
   c->thick[Na] = g->thick_0;
   c->m[Na] = c->thick[Na] * rho_l;
   c->H_abs[Na] = c->m[Na] * g->T_bottom * c_l;
-  c->S_abs[Na] = c->m[Na] * g->S_bu_bottom;
+  c->S_abs[Na] = c->m[Na] * c->S_bu_bottom;
 }
 
 /* bottom_melt_simple, mo_layer_dynamics.f90:573-591 */
@@ -1076,7 +1093,7 @@ static void sub_test4(double time, double *fl_q_bottom) {
 /* linear interpolation in the 3-hourly tables; time_input(k) = (k-1)*3600*3, mo_functions.f90:323-325 */
 static double time_input(int k) { return ((double)(float)k - 1.0) * 3600.0 * 3.0; }
 
-/* sub_heat_fluxes, mo_heat_fluxes.f90:69-312 (boundflux_flag 1 and 2) */
+/* sub_heat_fluxes, mo_heat_fluxes.f90:69-312 (boundflux_flag 1, 2, and 3 without lab snow) */
 static void sub_heat_fluxes(column *c) {
   const samsim_config *g = c->cfg;
   int N = c->N, Na = c->N_active, k, tc = c->time_counter;
@@ -1157,6 +1174,16 @@ static void sub_heat_fluxes(column *c) {
     }
   }
 
+  if (g->boundflux_flag == 3) {                                                       /* :202-219, lab_snow_flag 0 */
+    c->T_freeze = dmin(oracle_func_T_freeze(c->S_abs[Na] / c->m[Na], g->salt_flag), 0.0);
+    c->T_top = T[1];
+    fl_Q[1] = g->alpha_flux_instable * (c->T_top - c->T2m);
+    if (fl_Q[1] < 0.0) {
+      c->T_top = dmax(c->T_freeze, T[1]);
+      fl_Q[1] = g->alpha_flux_stable * (c->T_top - c->T2m);
+    }
+  }
+
   fl_Q[Na + 1] = c->fl_q_bottom;                                                      /* :262 */
 
   s = 0.0; for (k = 1; k <= N; k++) s += H_abs[k];
@@ -1193,7 +1220,7 @@ void oracle_flood_simple(double freeboard, double *S_abs1, double *H_abs1, doubl
                          double S_bu_bottom, double psi_g_snow, double *H_abs_snow, double *m_snow, double *thick_snow) {
   samsim_config g; column c; double S[2], H[2], m[2], th[2];
   memset(&g, 0, sizeof g); memset(&c, 0, sizeof c);
-  g.T_bottom = T_bottom; g.S_bu_bottom = S_bu_bottom;
+  g.T_bottom = T_bottom; g.S_bu_bottom = S_bu_bottom; c.S_bu_bottom = S_bu_bottom;
   S[1] = *S_abs1; H[1] = *H_abs1; m[1] = *m1; th[1] = *thick1;
   c.cfg = &g; c.S_abs = S; c.H_abs = H; c.m = m; c.thick = th;
   c.freeboard = freeboard; c.psi_g_snow = psi_g_snow; c.H_abs_snow = *H_abs_snow; c.m_snow = *m_snow; c.thick_snow = *thick_snow;
@@ -1326,7 +1353,7 @@ static void take_snapshot(column *c) {
   s[SAMSIM_S_FL_SW] = c->fl_sw; s[SAMSIM_S_FL_LW] = c->fl_lw; s[SAMSIM_S_MELT_THICK_SNOW] = c->melt_thick_snow;
   s[SAMSIM_S_FL_Q_SNOW] = c->fl_Q_snow;
   s[SAMSIM_S_ENERGY_STORED] = c->energy_stored; s[SAMSIM_S_FRESHWATER] = c->freshwater; s[SAMSIM_S_TOTAL_RESIST] = c->total_resist;
-  s[SAMSIM_S_THICKNESS] = c->thickness; s[SAMSIM_S_BULK_SALIN] = c->bulk_salin; s[SAMSIM_S_FL_REST] = c->fl_rest;
+  s[SAMSIM_S_THICKNESS] = c->thickness; s[SAMSIM_S_BULK_SALIN] = c->bulk_salin; s[SAMSIM_S_FL_REST] = c->fl_rest; s[SAMSIM_S_S_BU_BOTTOM] = c->S_bu_bottom;
   s[SAMSIM_S_DT2M] = c->dT2m; s[SAMSIM_S_PRECIP_SCALE] = c->precip_scale;
   c->snap_valid = 1; c->snap_time = c->time; c->snap_step = c->step + 1; c->snap_N_active = c->N_active;
 }
@@ -1362,7 +1389,7 @@ static void step_part_b(column *c) {
   if (c->psi_g[Na] > 0.0) {
     temp2 = c->psi_g[Na] * thick[Na] * rho_l;
     m[Na] = m[Na] + temp2;
-    S_abs[Na] = S_abs[Na] + temp2 * g->S_bu_bottom;
+    S_abs[Na] = S_abs[Na] + temp2 * c->S_bu_bottom;
     H_abs[Na] = H_abs[Na] + temp2 * c_l * g->T_bottom;
   }
 
@@ -1379,7 +1406,7 @@ static void step_part_b(column *c) {
   }
 
   /* bottom turbulence :450-457 */
-  if (g->turb_flag == 2) sub_turb_flux(g->T_bottom, g->S_bu_bottom, c->T[Na], &S_abs[Na], m[Na], g->dt);
+  if (g->turb_flag == 2) sub_turb_flux(g->T_bottom, c->S_bu_bottom, c->T[Na], &S_abs[Na], m[Na], g->dt);
 
   /* gravity drainage :463-477 */
   if (g->grav_flag == 2 && Na > 1) { fl_grav_drain(c); CHECK(); }
@@ -1390,6 +1417,17 @@ static void step_part_b(column *c) {
   else if (g->testcase == 3) { c->liquid_precip = 0.0; c->solid_precip = 0.15 / 86400.0 / 356.0; }  /* sub_test3, :172-187 */
   else if (g->testcase == 4 || g->testcase == 7) sub_test4(c->time, &c->fl_q_bottom);
   else if (g->testcase == 5 && c->step + 1 == 2) { for (k = 1; k <= N; k++) S_abs[k] = 5.0 * m[k]; }   /* mo_grotz.f90:543-544 */
+  else if (g->testcase == 2) sub_test2(c->time, &c->T2m);
+  else if (g->testcase == 6) sub_test6(c->time, &c->T2m);
+  else if (g->testcase == 9) sub_test9(c->time, &c->T2m);
+
+  /* tank: the water below the ice holds what salt the ice does not, mo_grotz.f90:573-575 */
+  if (g->tank_flag == 2) {
+    double sS = 0.0, sm = 0.0;
+    for (k = 1; k <= N; k++) sS += S_abs[k];
+    for (k = 1; k <= N; k++) sm += m[k];
+    c->S_bu_bottom = (g->S_total - sS) / (g->m_total - sm);
+  }
 
   /* heat fluxes :584 */
   sub_heat_fluxes(c); CHECK();
@@ -1407,8 +1445,21 @@ static void step_part_b(column *c) {
   snow_block(c); CHECK();                                                             /* :604-624 */
   c->melt_thick_snow = c->melt_thick_snow_old + c->melt_thick_snow;                   /* :625 */
 
-  /* flushing preparations :632-664 (boundflux_flag 2 only; 3 is out of scope) */
+  /* flushing preparations :632-664 */
   if (Na > 1 && g->flush_flag > 2) {
+    if (g->boundflux_flag == 3) {                                                     /* :649-663: T2m in place of T_top */
+      c->T_freeze = oracle_func_T_freeze(S_abs[1] / m[1], g->salt_flag);
+      c->melt_thick = 0.0;
+      if (freeboard_now(c) > 0.0000000000001) {
+        if (c->psi_s[1] < psi_s_top_min || c->T2m >= c->T_freeze) {
+          sub_melt_thick(c->psi_l[1], c->psi_s[1], c->psi_g[1], c->T[1], c->T_freeze, c->T2m, c->fl_Q[1], c->thick_snow,
+                         g->dt, &c->melt_thick, &thick[1], g->thick_min);
+          c->melt_thick = dmax(c->melt_thick, 0.0);
+          if (c->thick_snow >= g->thick_min / 100.0 && c->melt_thick > 0.00000000001 && c->melt_thick_snow == 0.0)
+            sub_melt_snow(&c->melt_thick, &thick[1], &c->thick_snow, &H_abs[1], &c->H_abs_snow, &m[1], &c->m_snow, &c->psi_g_snow);
+        }
+      }
+    }
     if (g->boundflux_flag == 2) {
       c->T_freeze = oracle_func_T_freeze(S_abs[1] / m[1], g->salt_flag);
       c->melt_thick = 0.0;
@@ -1464,7 +1515,7 @@ static void step_part_b(column *c) {
     }
     Na = c->N_active;
     if (Na < N && thick[(Na + 1 < N) ? Na + 1 : N] == 0.0) {                          /* :772-783 scrub */
-      c->T[Na + 1] = g->T_bottom; c->S_bu[Na + 1] = g->S_bu_bottom; c->H[Na + 1] = 0.0;
+      c->T[Na + 1] = g->T_bottom; c->S_bu[Na + 1] = c->S_bu_bottom; c->H[Na + 1] = 0.0;
       c->psi_l[Na + 1] = 1.0; c->psi_s[Na + 1] = 0.0;
     }
   } else {
@@ -1522,7 +1573,7 @@ int oracle_create(const samsim_config *cfg, int64_t ncol, oracle_handle **out) {
     c->flush_v = lay_alloc(N); c->flush_h = lay_alloc(N);
     /* mo_init.f90:1982-1990 */
     for (int k = 1; k <= N; k++) { c->T[k] = cfg->T_bottom; c->S_bu[k] = cfg->S_bu_bottom; c->psi_l[k] = 1.0; }
-    c->time_counter = 1; c->precip_scale = 1.0;
+    c->time_counter = 1; c->precip_scale = 1.0; c->S_bu_bottom = cfg->S_bu_bottom;
   }
   h->out_col0 = 0; h->out_ncols = 1;
   h->cols[0].snap_lay = (double *)calloc((size_t)SAMSIM_NARR * N, sizeof(double));
@@ -1582,6 +1633,7 @@ static double *scal_slot(column *c, int idx) {
     case SAMSIM_S_TOTAL_RESIST: return &c->total_resist; case SAMSIM_S_THICKNESS: return &c->thickness;
     case SAMSIM_S_BULK_SALIN: return &c->bulk_salin;
     case SAMSIM_S_FL_REST: return &c->fl_rest;
+    case SAMSIM_S_S_BU_BOTTOM: return &c->S_bu_bottom;
     case SAMSIM_S_DT2M: return &c->dT2m; case SAMSIM_S_PRECIP_SCALE: return &c->precip_scale;
   }
   return NULL;
@@ -1611,6 +1663,7 @@ int oracle_set_state(oracle_handle *h, const samsim_state_soa *s, int64_t col0) 
     }
     /* the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing and are not touched by set_state */
     for (int j = 0; j < SAMSIM_S_DT2M; j++) *scal_slot(c, j) = s->scal[(size_t)j * nc + i];
+    if (h->cfg.tank_flag != 2) c->S_bu_bottom = h->cfg.S_bu_bottom;
     c->N_active = s->n_active[i];
     if (c->N_active < 1 || c->N_active > N) return SAMSIM_ERR_ARG;
   }

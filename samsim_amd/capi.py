@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _CFG_INT_FIELDS = [
     "struct_size", "testcase", "nlayer", "n_top", "n_middle", "n_bottom",
@@ -25,7 +25,7 @@ _CFG_INT_FIELDS = [
 ]
 _CFG_DBL_FIELDS = [
     "dt", "thick_0", "thick_min", "T_bottom", "S_bu_bottom", "k_snow_flush", "max_flux_plate", "time_out",
-    "time_total",
+    "time_total", "alpha_flux_instable", "alpha_flux_stable", "m_total", "S_total",
 ]
 
 
@@ -65,7 +65,7 @@ SCALARS = [
     "phi_s", "T_top", "melt_thick", "T2m", "liquid_precip", "solid_precip", "fl_q_bottom",
     "grav_drain", "grav_salt", "grav_temp", "melt_out1", "melt_out2", "melt_out3", "melt_err",
     "freeboard", "T_freeze", "albedo", "fl_sw", "fl_lw", "melt_thick_snow", "fl_Q_snow",
-    "energy_stored", "freshwater", "total_resist", "thickness", "bulk_salin", "fl_rest", "dT2m", "precip_scale",
+    "energy_stored", "freshwater", "total_resist", "thickness", "bulk_salin", "fl_rest", "S_bu_bottom", "dT2m", "precip_scale",
 ]
 S = {n: i for i, n in enumerate(SCALARS)}
 NSCAL = len(SCALARS)

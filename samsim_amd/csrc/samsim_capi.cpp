@@ -74,13 +74,14 @@ int validate(const samsim_config &c) {
   if (c.n_top < 3 || c.n_bottom < 1 || c.n_middle < 1 || c.n_top + c.n_middle + c.n_bottom != c.nlayer) return SAMSIM_ERR_ARG;
   if (!(c.dt > 0.0) || !(c.thick_0 > 0.0) || c.i_time_out < 0) return SAMSIM_ERR_ARG;
   auto in = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
-  if (!in(c.boundflux_flag, {1, 2})) return SAMSIM_ERR_UNSUPPORTED;
+  if (!in(c.boundflux_flag, {1, 2, 3}) || (c.boundflux_flag == 3 && c.lab_snow_flag != 0)) return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.atmoflux_flag, {1, 2, 3})) return SAMSIM_ERR_UNSUPPORTED;
+  if (c.tank_flag == 2 && !(c.m_total > 0.0)) return SAMSIM_ERR_ARG;
   if (!in(c.grav_flag, {1, 2, 3}) || c.prescribe_flag != 1 || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 4, 5}) || !in(c.flood_flag, {1, 2, 3}))
     return SAMSIM_ERR_UNSUPPORTED;
-  if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || c.tank_flag != 1)
+  if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || !in(c.tank_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.albedo_flag, {1, 2}) || !in(c.freeboard_snow_flag, {0, 1}) || !in(c.snow_flush_flag, {0, 1}) || c.bgc_flag != 1)
     return SAMSIM_ERR_UNSUPPORTED;
@@ -281,6 +282,7 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_S_BU * N * nc, N * nc, cfg->S_bu_bottom, h->stream), "fill S_bu");
     ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_PSI_L * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
     ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream), "fill precip_scale");
+    ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_S_BU_BOTTOM * nc, nc, cfg->S_bu_bottom, h->stream), "fill S_bu_bottom");
     if (ok) {
       hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->n_active, nc, 1);
       hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, h->flags, nc,

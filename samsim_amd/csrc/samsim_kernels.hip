@@ -53,6 +53,46 @@ constexpr double Turb_B = 0.05;
 // 101 ms, by value (struct copied in and out) 209 ms, everything inline 90 ms per launch of the default bench.
 #define RARE __forceinline__
 
+// ---------------------------------------------------------------- kernel instantiations
+// The step kernel is instantiated per flag set K.  KGeneric reads every flag of samsim_config at run time and contains
+// all supported parametrisations.  A fixed set (KSheba = testcase 4 as shipped = BASELINE cfg3 / cfg5, KPlate = testcase 1 =
+// cfg1 / cfg2) turns the flags into compile-time constants: the branches of the other parametrisations, their registers
+// and the flag loads disappear from the hot sweeps.  samsim_launch_step picks the instantiation whose flags equal the
+// handle's configuration, KGeneric otherwise; the code paths taken are the same either way.
+#define SAMSIM_FLAG_LIST(X)                                                                                               \
+  X(atmoflux_flag) X(grav_flag) X(prescribe_flag) X(grav_heat_flag) X(flush_heat_flag) X(turb_flag) X(salt_flag)         \
+  X(boundflux_flag) X(flush_flag) X(flood_flag) X(bottom_flag) X(precip_flag) X(harmonic_flag) X(tank_flag) X(albedo_flag) \
+  X(lab_snow_flag) X(freeboard_snow_flag) X(snow_flush_flag) X(snow_precip_flag) X(testcase)
+struct KGeneric {
+  static constexpr bool fixed = false, general = true;
+#define X(f) [[maybe_unused]] static constexpr int f = 0;
+  SAMSIM_FLAG_LIST(X)
+#undef X
+};
+struct KSheba {  // init(4), mo_init.f90:1127-1207 on the defaults of :83-109
+  static constexpr bool fixed = true, general = false;
+  static constexpr int atmoflux_flag = 2, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 2, turb_flag = 2,
+                       salt_flag = 1, boundflux_flag = 2, flush_flag = 5, flood_flag = 2, bottom_flag = 1, precip_flag = 1,
+                       harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
+                       snow_flush_flag = 1, snow_precip_flag = 1, testcase = 4;
+};
+struct KPlate {  // init(1), mo_init.f90:865-945 (bgc off)
+  static constexpr bool fixed = true, general = false;
+  static constexpr int atmoflux_flag = 1, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 1, turb_flag = 1,
+                       salt_flag = 2, boundflux_flag = 1, flush_flag = 1, flood_flag = 2, bottom_flag = 1, precip_flag = 0,
+                       harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
+                       snow_flush_flag = 1, snow_precip_flag = 1, testcase = 1;
+};
+template <class K>
+bool flags_match(const samsim_config &g) {
+#define X(f) if (g.f != K::f) return false;
+  SAMSIM_FLAG_LIST(X)
+#undef X
+  return true;
+}
+// flag read inside a function template over K with `g` = the run-time configuration in scope
+#define CFG(f) (K::fixed ? K::f : g.f)
+
 // Device data pointers carry the global address space in their type: an access through them is a global_load / global_store
 // even where the pointer itself has been through memory (a struct passed to a non-inlined function), where the compiler
 // would otherwise have to assume a generic (flat) address.
@@ -277,15 +317,18 @@ struct Ctx {
   long long out_col0, out_ncols;
   Salt salt;
   double p17, p14, tf_c3;
+  // salinity of the water below the ice: cfg.S_bu_bottom (uniform), or the column's tank budget with tank_flag 2 (mo_grotz.f90:573)
+  double S_bu_bottom;
 };
 
 
 // ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
 // O(N): one pass for the column totals, one pass for the waterline search with prefix sums (the reference
 // recomputes the suffix sums for every candidate layer).
+template <class K>
 __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
-  double snowmass = (x.p->cfg.freeboard_snow_flag == 0) ? c.m_snow : 0.0;
+  double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? c.m_snow : 0.0;
   double A = 0.0, G = 0.0;
   for (int k = 1; k <= Na; ++k) {
     double th = LAY(SAMSIM_A_THICK, k);
@@ -322,6 +365,7 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
 // ---------------------------------------------------------------- snow, mo_snow.f90
 // snow_coupling, mo_snow.f90:61-104.  The reference passes T_snow / T as both the guess and the result of getT;
 // by-reference argument passing makes the guess H/c_l (getT's first statement overwrites it).
+template <class K>
 __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
   const Salt &s = x.salt;
   double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), S_bu = LAY(SAMSIM_A_S_BU, 1);
@@ -369,12 +413,13 @@ __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
 
 
 // snow_precip (mo_snow.f90:123-150) and snow_precip_0 (:167-192), called from mo_grotz.f90:251-265
+template <class K>
 __device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   if (!(dmax(c.liquid_precip, c.solid_precip) > 0.0)) return;
   const double dt = g.dt, T2m = c.T2m;
   double solid, liquid;
-  if (g.precip_flag == 0) { solid = c.solid_precip; liquid = c.liquid_precip; }
+  if (CFG(precip_flag) == 0) { solid = c.solid_precip; liquid = c.liquid_precip; }
   else if (T2m > 0.0) { solid = 0.0; liquid = c.liquid_precip; }
   else { solid = c.liquid_precip; liquid = 0.0; }
   if (c.Na > 1) {
@@ -397,6 +442,7 @@ __device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
 
 // snow_thermo (mo_snow.f90:212-320) / snow_thermo_meltwater (:331-454) wrapped in the block of
 // mo_grotz.f90:273-292 and :604-624
+template <class K>
 __device__ RARE void snow_block(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   if (!(c.thick_snow > 0.0)) {
@@ -405,7 +451,7 @@ __device__ RARE void snow_block(Col &c, const Ctx &x) {
     return;
   }
   c.melt_thick_snow = 0.0;
-  const bool meltwater = (g.snow_flush_flag == 1);
+  const bool meltwater = (CFG(snow_flush_flag) == 1);
   double m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1), H_abs = LAY(SAMSIM_A_H_ABS, 1);
   bool touched = false;
   double phi_snow = 0.0, max_lwc, max_lwc_v, sat_snow;
@@ -526,6 +572,7 @@ __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m
 // Permeability + Rayleigh number of layer k from its T, phi (Expulsion evaluated in registers).  Only PHI (by the caller)
 // and ray are stored: the down sweep re-evaluates Expulsion from PHI, m and thick (same inputs, same operations) and
 // writes the psi arrays itself, which is cheaper than handing psi_s, psi_l, psi_g and V_ex over through HBM.
+template <class K>
 __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bool do_ray, double T, double phi, double S_bu,
                                          double m, double thick, RayScan &r) {
   const samsim_config &g = x.p->cfg;
@@ -548,7 +595,7 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       r.st = r.st + thick;
       double ray;
       const double d_S_br = S_br - r.S_br_bot;
-      if (g.harmonic_flag == 2) {
+      if (CFG(harmonic_flag) == 2) {
         const double hp = (r.minp < x.p14) ? 0.0 : (r.st + r.bot) / (r.stp + r.botterm);
         ray = grav_f * rho_l * bbeta * d_S_br * height * hp;
       } else {
@@ -561,11 +608,12 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
   }
 }
 
+template <class K>
 __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
-  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
+  const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   double T_test = g.T_bottom;
   RayScan r;
   ray_scan_init(r);
@@ -589,7 +637,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
     LAY(SAMSIM_A_T, k) = T;
     LAY(SAMSIM_A_PHI, k) = phi;
-    s1_layer(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
+    s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
   }
   c.min_psi_s = r.min_psi_s;
   c.buoy_s = r.buoy_s;
@@ -598,11 +646,12 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
 
 // Layer 1 of the first sweep when layers N_active..2 were already done by the previous step's up sweep
 // (their prognostic values have not changed since).  The scan state comes from the hand-over block.
+template <class K>
 __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const size_t nc = c.ncol;
-  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
+  const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   RayScan r;
   r.minp = c.spec[SP_MINP * nc]; r.stp = c.spec[SP_STP * nc]; r.st = c.spec[SP_ST * nc];
   r.bot = c.spec[SP_BOT * nc]; r.botterm = c.spec[SP_BOTTERM * nc]; r.perm_bot = c.spec[SP_PERM_BOT * nc];
@@ -617,7 +666,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
-  s1_layer(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, r);
+  s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, r);
   c.min_psi_s = r.min_psi_s;
   c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, 1);
@@ -627,6 +676,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
 // expulsion_flux (mo_mass.f90:112-136): downward brine flux recurrence, m and psi_g update.  mass_transfer
 // (mo_mass.f90:53-96) with these fluxes (all <= 0: brine only moves down) needs the layer above only.  Then the
 // S_bu refresh of mo_grotz.f90:333-335.  mass_transfer is skipped on the first step (mo_grotz.f90:313).
+template <class K>
 __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   const int Na = c.Na;
   const bool transfer = (c.step + 1 != 1);
@@ -687,6 +737,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- vital signs, mo_grotz.f90:192-223 (output only)
+template <class K>
 __device__ RARE void vital_signs(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
@@ -720,6 +771,7 @@ __device__ RARE void vital_signs(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- flood, mo_flood.f90:55-151
+template <class K>
 __device__ RARE void flood(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
@@ -758,7 +810,7 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   if (freeboard + shift_ice < neg_free) {
     const double shift = neg_free - (freeboard + shift_ice);
     flood_brine = shift * (psi_g_snow) * rho_l;
-    SN = SN + (g.S_bu_bottom - S_buN) * flood_brine;
+    SN = SN + (x.S_bu_bottom - S_buN) * flood_brine;
     HN = HN + (g.T_bottom - TN) * c_l * flood_brine;
     S1 = S1 + S_buN * flood_brine;
     H1 = H1 + TN * c_l * flood_brine;
@@ -779,13 +831,14 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- flood_simple, mo_flood.f90:167-210 (flood_flag 3)
+template <class K>
 __device__ RARE void flood_simple(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const double shift = c.freeboard - neg_free;
   const double flood_brine = -shift * c.psi_g_snow * rho_l;
   double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
   th1 = th1 - shift;
-  S1 = S1 + g.S_bu_bottom * flood_brine;
+  S1 = S1 + x.S_bu_bottom * flood_brine;
   H1 = H1 - shift / c.thick_snow * c.H_abs_snow;
   H1 = H1 + g.T_bottom * c_l * flood_brine;
   m1 = m1 - shift / c.thick_snow * c.m_snow;
@@ -800,10 +853,11 @@ __device__ RARE void flood_simple(Col &c, const Ctx &x) {
 }
 
 // recompute ray(1) after flood changed thick(1) (thick(1) enters only the k = 1 harmonic mean)
+template <class K>
 __device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
-  if (g.harmonic_flag != 2) return;  // MINVAL variant does not depend on thick(1)
+  if (CFG(harmonic_flag) != 2) return;  // MINVAL variant does not depend on thick(1)
   double minp = 1.0e300, stp = 0.0, st = 0.0, height = 0.0;
   const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
   const double bot = thN * psN / psi_s_min;
@@ -828,6 +882,7 @@ __device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
 // (mo_mass.f90:53-96) with fl_m(k+1) = fl_up(k) >= 0.  mass_transfer reads the salt of the layer BELOW after the
 // drainage loop (snapshot SS_abs), so layer k+1 is drained one iteration ahead of the transfer into layer k.
 // The same pass multiplies up the Beer-law transmittance for fl_rad(N_active) (mo_heat_fluxes.f90:151-155).
+template <class K>
 __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double beer0) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
@@ -890,7 +945,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
       nxt = drain(k + 1);
       T_below = nxt.T; S_bu_below = nxt.S_bu; SS_abs_below = nxt.S_abs;
     } else {
-      T_below = g.T_bottom; S_bu_below = g.S_bu_bottom; SS_abs_below = g.S_bu_bottom * 2000.0;
+      T_below = g.T_bottom; S_bu_below = x.S_bu_bottom; SS_abs_below = x.S_bu_bottom * 2000.0;
     }
     if (cur.flup > 0.0) {  // fl_m(k+1) > 0: inflow from below
       cur.H_abs = cur.H_abs + cur.flup * T_below * c_l;
@@ -904,7 +959,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     }
     if (k == Na) {
       c.grav_drain = c.grav_drain + cur.flup;
-      if (g.grav_heat_flag == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
+      if (CFG(grav_heat_flag) == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
     }
     if (cur.ch) {
       LAY(SAMSIM_A_S_ABS, k) = cur.S_abs;
@@ -922,6 +977,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
 
 // fl_grav_drain_simple (mo_grav_drain.f90:218-278, grav_flag 3) with ray(k) from S1: every layer above the critical
 // Rayleigh number loses 1 % of its salt (`0.99` is a default-REAL literal); fused with the Beer-law pass like P3.
+template <class K>
 __device__ RARE void sweep_grav_drain_simple(Col &c, bool do_beer, double beer0) {
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
@@ -938,6 +994,7 @@ __device__ RARE void sweep_grav_drain_simple(Col &c, bool do_beer, double beer0)
 }
 
 // Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
+template <class K>
 __device__ RARE void sweep_beer(Col &c, double beer0) {
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
@@ -958,6 +1015,7 @@ __device__ RARE void sweep_beer(Col &c, double beer0) {
 // A(j) of the reference runs for all layers before B starts, but A(j) only reads layers <= j and B/C(j-1) only layers
 // j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
 // T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
+template <class K>
 __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
@@ -1026,12 +1084,12 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
         const double t2 = psi_g * thick * rho_l;
         m = m + t2;
-        S_abs = S_abs + t2 * g.S_bu_bottom;
+        S_abs = S_abs + t2 * x.S_bu_bottom;
         H_abs = H_abs + t2 * c_l * g.T_bottom;
       }
-      if (g.turb_flag == 2) {  // sub_turb_flux
-        const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * dt;
-        S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+      if (CFG(turb_flag) == 2) {  // sub_turb_flux
+        const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, x.S_bu_bottom) + func_density(T, S_abs / m))) * dt;
+        S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       }
     }
     // ---- B(j)
@@ -1078,14 +1136,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
     prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
-    prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, g.T_bottom, g.S_bu_bottom), g.S_bu_bottom * 2000.0);
+    prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, g.T_bottom, x.S_bu_bottom), x.S_bu_bottom * 2000.0);
   }
   if (flup_pp > 0.0) {
     prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
     prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
   }
   c.grav_drain = c.grav_drain + prev.flup;
-  if (g.grav_heat_flag == 2) prev.H_abs = prev.H_abs + heat_loss - prev.flup * c_l * g.T_bottom;
+  if (CFG(grav_heat_flag) == 2) prev.H_abs = prev.H_abs + heat_loss - prev.flup * c_l * g.T_bottom;
   LAY(SAMSIM_A_M, Na) = prev.m;
   LAY(SAMSIM_A_S_ABS, Na) = prev.S_abs;
   LAY(SAMSIM_A_H_ABS, Na) = prev.H_abs;
@@ -1099,14 +1157,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
 
 // ---------------------------------------------------------------- surface energy balance, mo_heat_fluxes.f90:77-195
 // sets fl_Q(1), T_top, fl_Q_snow, albedo, fl_sw, fl_lw, T_freeze; returns the Beer-law surface value temp2
-// GEN = false: the instantiation for the primary configurations (forcing tables or cooling plate, grav_flag 1/2, flush_flag
+// K::general = false: the instantiation for the primary configurations (forcing tables or cooling plate, grav_flag 1/2, flush_flag
 // 1/5, flood_flag 1/2, testcases without layer-array specifics); the secondary parametrisations compile away there.
-template <bool GEN>
+template <class K>
 __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
-  if (g.boundflux_flag != 2) return 0.0;
-  c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, g.albedo_flag);
-  if (!GEN || g.atmoflux_flag == 2) {
+  if (CFG(boundflux_flag) != 2) return 0.0;
+  c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, CFG(albedo_flag));
+  if (!K::general || CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
       c.fl_sw = x.f_sw[tc - 1];
       c.fl_lw = x.f_lw[tc - 1];
@@ -1115,7 +1173,7 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
       c.fl_sw = (1.0 - temp) * x.f_sw[tc - 2] + temp * x.f_sw[tc - 1];
       c.fl_lw = (1.0 - temp) * x.f_lw[tc - 2] + temp * x.f_lw[tc - 1];
     }
-  } else if (g.atmoflux_flag == 1) {
+  } else if (CFG(atmoflux_flag) == 1) {
     // sub_notzflux(time + 180 days), mo_functions.f90:270-289 (47.9, 53.1 are default-REAL literals); fl_rest lives in
     // the scalar block (atmoflux_flag 3 leaves fl_sw and fl_rest as the caller set them)
     double day = (time + 86400.0 * 180.0) / 86400.0;
@@ -1129,22 +1187,32 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
   return pen * (1.0 - c.albedo) * c.fl_sw;
 }
 
-template <bool GEN>
+template <class K>
 __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
   const double thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   const double k1 = psi_s1 * k_s + psi_l1 * k_l + psi_g1 * 0.0;
-  if (g.boundflux_flag == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
+  if (CFG(boundflux_flag) == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
     double fl = (T1 - c.T_top) / (thick1 / (2.0 * k1));
     if (fabs(fl) > g.max_flux_plate) fl = fl / fabs(fl) * g.max_flux_plate;
     c.fl_Q1 = fl;
     return;
   }
+  if (K::general && CFG(boundflux_flag) == 3) {  // lab air temperature, mo_heat_fluxes.f90:202-219 (lab_snow_flag 0)
+    c.T_freeze = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
+    c.T_top = T1;
+    c.fl_Q1 = g.alpha_flux_instable * (c.T_top - c.T2m);
+    if (c.fl_Q1 < 0.0) {
+      c.T_top = dmax(c.T_freeze, T1);
+      c.fl_Q1 = g.alpha_flux_stable * (c.T_top - c.T2m);
+    }
+    return;
+  }
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
-  const double fl_rest = (!GEN || g.atmoflux_flag == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
+  const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
   double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
@@ -1161,7 +1229,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   c.T_top = temp1;
 
   if (c.thick_snow >= thick_min / 100.0) c.T_freeze = 0.0;
-  else c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
+  else c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
 
   const double k_snow = (c.thick_snow >= thick_min / 100.0) ? func_k_snow(c.m_snow, c.thick_snow) : 0.0;
   // sub_fl_Q_snow, mo_snow.f90:498-518
@@ -1195,6 +1263,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
 // freeboard, flush3) still need the current ones.  Layer 1 is left to prologue_top_layer: snow, melt water and the
 // regrid trigger all act on it between the two steps.  If flushing or a regrid changes deeper layers afterwards, the
 // column is flagged COLF_DIRTY and the next step runs the full first sweep instead.
+template <class K>
 __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
@@ -1202,7 +1271,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   const size_t nc = c.ncol;
   const double dt = g.dt, thick_min = g.thick_min;
   const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
-  const bool do_ray = (g.grav_flag >= 2 && Na > 1);
+  const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   const bool keep_ray = next_is_output && col >= x.out_col0 && col < x.out_col0 + x.out_ncols;
   const double H_abs_snow_before = c.H_abs_snow;
   double sum_before = 0.0, sum_after = 0.0;
@@ -1242,7 +1311,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       if (thin_snow) {
         c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
         LAY(SAMSIM_A_H_ABS, 1) = H_abs;
-        snow_coupling(c, x);
+        snow_coupling<K>(c, x);
         if (c.status) return;
         H_abs = LAY(SAMSIM_A_H_ABS, 1);
       } else if (c.thick_snow >= thick_min) {
@@ -1267,7 +1336,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      s1_layer(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
     }
     flq_below = flq_k;
     T_k = T_u; th_k = th_u; hr_k = hr_u;
@@ -1308,6 +1377,7 @@ __device__ __forceinline__ void sub_melt_thick(double psi_l, double psi_s, doubl
 }
 
 // ---------------------------------------------------------------- flush3, mo_flush.f90:70-237
+template <class K>
 __device__ RARE void flush3(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
@@ -1322,13 +1392,13 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   c.melt_thick = dmin(c.melt_thick, g.thick_0 / 3.0);
 
   // permeability and bottom -> top equivalent resistance R(k) (stored in the V_ex scratch rows)
-  const double pfill = (g.snow_flush_flag == 1) ? 0.0 : 1.0;
+  const double pfill = (CFG(snow_flush_flag) == 1) ? 0.0 : 1.0;
   for (int k = Na + 1; k <= N; ++k) LAY(SAMSIM_A_PERM, k) = pfill;
   double R_below = 0.0;  // R(k+1)
   for (int k = Na; k >= 1; --k) {
     const double thick = LAY(SAMSIM_A_THICK, k);
     double perm;
-    if (g.snow_flush_flag == 1) {
+    if (CFG(snow_flush_flag) == 1) {
       perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k) + 2.0 * LAY(SAMSIM_A_PSI_G, k)));
       if (perm == 0.0) perm = 1.0;
     } else {
@@ -1387,12 +1457,12 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     fv_up = fv;
     if (k == Na) {
       S_bu_N = S_bu;
-      if (g.flush_heat_flag == 2) H_abs = H_abs - flm_next * T * c_l;
+      if (CFG(flush_heat_flag) == 2) H_abs = H_abs - flm_next * T * c_l;
       // horizontal contributions of the layers above, then the loss of all horizontal brine
       H_abs = H_abs + accH;
       S_abs = S_abs + accS;
       const double loss_S = sum_fh * S_bu_N, loss_H = sum_fh * T * c_l;
-      if (g.flush_heat_flag == 2) H_abs = H_abs - loss_H;
+      if (CFG(flush_heat_flag) == 2) H_abs = H_abs - loss_H;
       S_abs = S_abs - loss_S;
     } else {
       if (k == 1) {
@@ -1430,16 +1500,19 @@ __device__ __forceinline__ LayerVals layer_vals(Col &c, int k) {
   v.H = LAY(SAMSIM_A_H_ABS, k) / m;
   return v;
 }
+template <class K>
 __device__ __forceinline__ void set_layer(Col &c, int k, const LayerVals &v, double thick_0) {
   LAY(SAMSIM_A_M, k) = v.rho * thick_0;
   LAY(SAMSIM_A_S_ABS, k) = v.S_bu * v.rho * thick_0;
   LAY(SAMSIM_A_H_ABS, k) = v.H * v.rho * thick_0;
 }
+template <class K>
 __device__ __forceinline__ void zero_layer(Col &c, int k) {
   LAY(SAMSIM_A_M, k) = 0.0; LAY(SAMSIM_A_S_ABS, k) = 0.0; LAY(SAMSIM_A_H_ABS, k) = 0.0; LAY(SAMSIM_A_THICK, k) = 0.0;
 }
 
 // top_melt, mo_layer_dynamics.f90:191-327
+template <class K>
 __device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
@@ -1455,13 +1528,13 @@ __device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
   LayerVals old_top1 = {0, 0, 0};
   if (have_mid) old_top1 = layer_vals(c, N_top + 1);
   const int kend = (N_top - 1 < Na - 1) ? N_top - 1 : Na - 1;
-  for (int k = 2; k <= kend; ++k) set_layer(c, k, layer_vals(c, k + 1), thick_0);  // reads old k+1 (not yet modified)
+  for (int k = 2; k <= kend; ++k) set_layer<K>(c, k, layer_vals(c, k + 1), thick_0);  // reads old k+1 (not yet modified)
   if (Na <= N_top) {
-    zero_layer(c, Na);
+    zero_layer<K>(c, Na);
     Na = Na - 1;
   } else if (Na > N_top && Na <= N && LAY(SAMSIM_A_THICK, N_top + 1) / thick_0 < 1.00001) {
-    for (int k = N_top; k <= Na - 1; ++k) set_layer(c, k, layer_vals(c, k + 1), thick_0);
-    zero_layer(c, Na);
+    for (int k = N_top; k <= Na - 1; ++k) set_layer<K>(c, k, layer_vals(c, k + 1), thick_0);
+    zero_layer<K>(c, Na);
     Na = Na - 1;
   }
   if (Na == N && LAY(SAMSIM_A_THICK, N_top + 1) - thick_0 >= 0.000001) {
@@ -1485,6 +1558,7 @@ __device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
 }
 
 // top_grow, mo_layer_dynamics.f90:607-716
+template <class K>
 __device__ __forceinline__ void top_grow(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
@@ -1502,12 +1576,12 @@ __device__ __forceinline__ void top_grow(Col &c, const Ctx &x) {
   if (Na > N_top && Na < N) kend = Na;  // second branch continues the same shift over N_top+1..Na
   for (int k = 2; k <= kend; ++k) {
     const LayerVals old_k = layer_vals(c, k);
-    set_layer(c, k, carry, thick_0);
+    set_layer<K>(c, k, carry, thick_0);
     carry = old_k;
   }
   if (Na <= N_top || (Na > N_top && Na < N)) {
     Na = Na + 1;
-    set_layer(c, Na, carry, thick_0);  // S_bu*thick_0*rho and S_bu*rho*thick_0 differ in association:
+    set_layer<K>(c, Na, carry, thick_0);  // S_bu*thick_0*rho and S_bu*rho*thick_0 differ in association:
     LAY(SAMSIM_A_S_ABS, Na) = carry.S_bu * thick_0 * carry.rho;  // mo_layer_dynamics.f90:660-661,674-675
     LAY(SAMSIM_A_H_ABS, Na) = carry.H * thick_0 * carry.rho;
     LAY(SAMSIM_A_THICK, Na) = thick_0;
@@ -1529,6 +1603,7 @@ __device__ __forceinline__ void top_grow(Col &c, const Ctx &x) {
 }
 
 // bottom_melt, mo_layer_dynamics.f90:341-427 (N_active == Nlayer)
+template <class K>
 __device__ __forceinline__ void bottom_melt(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
@@ -1557,6 +1632,7 @@ __device__ __forceinline__ void bottom_melt(Col &c, const Ctx &x) {
 }
 
 // bottom_growth, mo_layer_dynamics.f90:438-523 (N_active == Nlayer)
+template <class K>
 __device__ __forceinline__ void bottom_growth(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle, N_bottom = g.n_bottom;
@@ -1580,24 +1656,25 @@ __device__ __forceinline__ void bottom_growth(Col &c, const Ctx &x) {
   const double mN = thN * rho_l;
   LAY(SAMSIM_A_M, N) = mN;
   LAY(SAMSIM_A_H_ABS, N) = mN * g.T_bottom * c_l;
-  LAY(SAMSIM_A_S_ABS, N) = mN * g.S_bu_bottom;
+  LAY(SAMSIM_A_S_ABS, N) = mN * x.S_bu_bottom;
 }
 
 // layer_dynamics, mo_layer_dynamics.f90:64-175: exactly one branch per call, in priority order
+template <class K>
 __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
-  const int N = c.N, Na = c.Na, N_top = g.n_top, bf = g.bottom_flag;
+  const int N = c.N, Na = c.Na, N_top = g.n_top, bf = CFG(bottom_flag);
   const double thick_0 = g.thick_0;
   const int km1 = (Na - 1 > 1) ? Na - 1 : 1;
   const double phi_Na = LAY(SAMSIM_A_PHI, Na), phi_km1 = LAY(SAMSIM_A_PHI, km1);
   const double phi_Nm1 = LAY(SAMSIM_A_PHI, N - 1), phi_N = LAY(SAMSIM_A_PHI, N);
   const double th_mid = LAY(SAMSIM_A_THICK, N_top + 1), th1 = LAY(SAMSIM_A_THICK, 1);
   if (phi_Nm1 <= psi_s_min / 2.0 && phi_Na < 0.00001 && Na == N && th_mid / thick_0 > 1.000001 && bf == 1) {
-    bottom_melt(c, x);
+    bottom_melt<K>(c, x);
   } else if (Na > 1 && Na < N && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && bf == 1) {
-    zero_layer(c, Na); c.Na = Na - 1;  // bottom_melt_simple, :573-591
+    zero_layer<K>(c, Na); c.Na = Na - 1;  // bottom_melt_simple, :573-591
   } else if (Na > 1 && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && (th_mid / thick_0) < 1.01 && bf == 1) {
-    zero_layer(c, Na); c.Na = Na - 1;
+    zero_layer<K>(c, Na); c.Na = Na - 1;
   } else if (phi_Na > psi_s_min && Na < N && bf == 1) {
     // bottom_growth_simple, :537-560
     const double mnew = thick_0 * rho_l;
@@ -1605,16 +1682,16 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_THICK, Na + 1) = thick_0;
     LAY(SAMSIM_A_M, Na + 1) = mnew;
     LAY(SAMSIM_A_H_ABS, Na + 1) = mnew * g.T_bottom * c_l;
-    LAY(SAMSIM_A_S_ABS, Na + 1) = mnew * g.S_bu_bottom;
+    LAY(SAMSIM_A_S_ABS, Na + 1) = mnew * x.S_bu_bottom;
   } else if (phi_N > psi_s_min && bf == 1) {
-    bottom_growth(c, x);
+    bottom_growth<K>(c, x);
   } else if (th1 > 1.5 * thick_0) {
     c.melt_out3 = c.melt_out3 - th1;
-    top_grow(c, x);
+    top_grow<K>(c, x);
     c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
   } else if (th1 < 0.5 * thick_0) {
     c.melt_out3 = c.melt_out3 - th1;
-    top_melt(c, x);
+    top_melt<K>(c, x);
     if (c.status) return;
     c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
   }
@@ -1622,11 +1699,11 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
 
 
 // ---------------------------------------------------------------- output snapshot, mo_grotz.f90:340-398
-template <bool GEN>
+template <class K>
 __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double time) {
   const samsim_config &g = x.p->cfg;
-  if (c.Na > 1) c.freeboard = func_freeboard(c, x); else c.freeboard = 0.0;
-  if (g.grav_flag == 2) {
+  if (c.Na > 1) c.freeboard = func_freeboard<K>(c, x); else c.freeboard = 0.0;
+  if (CFG(grav_flag) == 2) {
     if (c.grav_drain == 0.0) c.grav_temp = 0.0; else c.grav_temp = c.grav_temp / c.grav_drain;
     c.grav_salt = c.grav_salt / g.time_out;
     c.grav_drain = c.grav_drain / g.time_out;
@@ -1655,8 +1732,9 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
-    OUT(SAMSIM_S_FL_REST, (g.boundflux_flag == 2 && (!GEN || g.atmoflux_flag == 2)) ? c.fl_lw + 0.0 + 0.0
+    OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? c.fl_lw + 0.0 + 0.0
                                                                         : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
+    OUT(SAMSIM_S_S_BU_BOTTOM, x.S_bu_bottom);
     OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
 #undef OUT
     x.out_n_active[oc] = c.Na;
@@ -1667,31 +1745,43 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
 }
 
 // testcase specifics that only touch scalars, mo_grotz.f90:503-565
-template <bool GEN>
+template <class K>
 __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g, double time) {
-  if (g.testcase == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
+  if (CFG(testcase) == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
     for (int n = 1; n <= 20; ++n) {
       if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
     }
-  } else if (GEN && g.testcase == 3) {  // sub_test3, :172-187
+  } else if (K::general && CFG(testcase) == 3) {  // sub_test3, :172-187
     c.liquid_precip = 0.0;
     c.solid_precip = 0.15 / 86400.0 / 356.0;
-  } else if (g.testcase == 4 || g.testcase == 7) {  // sub_test4, :197-202
+  } else if (CFG(testcase) == 4 || CFG(testcase) == 7) {  // sub_test4, :197-202
     c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+  } else if (K::general && CFG(testcase) == 2) {  // sub_test2, :99-111
+    if (time > 86400.0 * 25.0) c.T2m = 15.0;
+    else if (time > 86400.0 * 15.0) c.T2m = 1.0;
+  } else if (K::general && CFG(testcase) == 9) {  // sub_test9, :121-136
+    if (time < 19.75 * 3600.0) c.T2m = 0.0;
+    else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) c.T2m = -15.0;
+    else c.T2m = 1.0;
+  } else if (K::general && CFG(testcase) == 6) {  // sub_test6, :211-232
+    const double t[8] = {1714.0, 1676.0, 1525.0, 1483.0, 1385.0, 1349.0, 1160.0, 1100.0};
+    for (int i = 0; i < 8; ++i) {
+      if (time > t[i] * 60.0) { c.T2m = (i == 0) ? -19.0 : ((i & 1) ? -5.0 : -18.0); break; }
+    }
   }
 }
 
 // The reference's order between expulsion and the heat fluxes, sweep by sweep: taken whenever something sits between
 // expulsion and gravity drainage (the output block, thin-snow coupling, a possible flooding event) or no Rayleigh-number
 // drainage runs at all; mo_grotz.f90:312-565.
-template <bool GEN>
+template <class K>
 __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool coupling,
                                   bool do_grav, bool do_beer) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, Na = c.Na;
-    sweep_expulsion_transfer(c, x);   // mo_grotz.f90:312-335
+    sweep_expulsion_transfer<K>(c, x);   // mo_grotz.f90:312-335
 
-    if (out_step) output_point<GEN>(c, x, col, time);  // mo_grotz.f90:340-398
+    if (out_step) output_point<K>(c, x, col, time);  // mo_grotz.f90:340-398
 
     // bottom-layer gas -> ocean water, mo_grotz.f90:405-410
     {
@@ -1699,67 +1789,67 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
       if (psi_gN > 0.0) {
         const double temp2 = psi_gN * LAY(SAMSIM_A_THICK, Na) * rho_l;
         LAY(SAMSIM_A_M, Na) = LAY(SAMSIM_A_M, Na) + temp2;
-        LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * g.S_bu_bottom;
+        LAY(SAMSIM_A_S_ABS, Na) = LAY(SAMSIM_A_S_ABS, Na) + temp2 * x.S_bu_bottom;
         LAY(SAMSIM_A_H_ABS, Na) = LAY(SAMSIM_A_H_ABS, Na) + temp2 * c_l * g.T_bottom;
       }
     }
     // thin-snow coupling, mo_grotz.f90:418-420
     if (coupling) {
-      snow_coupling(c, x);
+      snow_coupling<K>(c, x);
       if (c.status) return;
     }
     // flooding, mo_grotz.f90:428-445
-    if (Na > 1 && g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0) {
+    if (Na > 1 && CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0) {
       // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
       // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
       const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
       if (c.m_snow > buoy) {
         c.freeboard = (buoy - c.m_snow) / rho_l;
-        if (c.freeboard < 0.0 && g.flood_flag == 2) {
-          flood(c, x);
-          if (g.grav_flag >= 2) refresh_ray_top(c, x);
-        } else if (GEN && g.flood_flag == 3 && c.freeboard < neg_free) {
-          flood_simple(c, x);
-          if (g.grav_flag >= 2) refresh_ray_top(c, x);
+        if (c.freeboard < 0.0 && CFG(flood_flag) == 2) {
+          flood<K>(c, x);
+          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
+        } else if (K::general && CFG(flood_flag) == 3 && c.freeboard < neg_free) {
+          flood_simple<K>(c, x);
+          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
         }
       }
     }
     // bottom turbulence, sub_turb_flux mo_functions.f90:347-363
-    if (g.turb_flag == 2) {
+    if (CFG(turb_flag) == 2) {
       const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
       double S_abs = LAY(SAMSIM_A_S_ABS, Na);
-      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, g.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
-      S_abs = S_abs - turb * (S_abs / m - g.S_bu_bottom);
+      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, x.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
+      S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       LAY(SAMSIM_A_S_ABS, Na) = S_abs;
     }
 
     // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
-    testcase_scalars<GEN>(c, g, time);
+    testcase_scalars<K>(c, g, time);
 
     // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
-    const double beer0 = radiation_header<GEN>(c, x, time, tc);
+    const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
     if (do_grav) {
-      sweep_grav_drain(c, x, do_beer, beer0);
+      sweep_grav_drain<K>(c, x, do_beer, beer0);
       if (c.status) return;
-    } else if (GEN && g.grav_flag == 3 && Na > 1) {
-      sweep_grav_drain_simple(c, do_beer, beer0);
+    } else if (K::general && CFG(grav_flag) == 3 && Na > 1) {
+      sweep_grav_drain_simple<K>(c, do_beer, beer0);
     } else if (do_beer) {
-      sweep_beer(c, beer0);
+      sweep_beer<K>(c, beer0);
     }
-    if (GEN && g.testcase == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
+    if (K::general && CFG(testcase) == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
       for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
     }
 }
 
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
-template <bool GEN>
-__device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
+template <class K>
+__device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N;
 
   if (out_step) {
-    vital_signs(c, x);  // mo_grotz.f90:192-223; only ever read by `output`
+    vital_signs<K>(c, x);  // mo_grotz.f90:192-223; only ever read by `output`
     // `output` prints the Rayleigh numbers of the PREVIOUS step's fl_grav_drain.  Normally the previous up sweep has
     // saved them before overwriting; on the first step after set_state the array itself still holds them.
     if ((c.flags & COLF_RESTART) && col >= x.out_col0 && col < x.out_col0 + x.out_ncols) {
@@ -1769,7 +1859,7 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
   }
 
   // forcing, mo_grotz.f90:229-241 (+ ensemble perturbation)
-  if (g.atmoflux_flag == 2) {
+  if (CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
       c.T2m = x.f_T2m[tc - 1];
       c.liquid_precip = x.f_precip[tc - 1];
@@ -1782,67 +1872,78 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
     c.liquid_precip = c.liquid_precip * c.precip_scale;
   }
 
-  snow_fall(c, x);                  // mo_grotz.f90:251-265
-  snow_block(c, x);                 // mo_grotz.f90:273-292
+  snow_fall<K>(c, x);                  // mo_grotz.f90:251-265
+  snow_block<K>(c, x);                 // mo_grotz.f90:273-292
   if (c.status) return;
 
   // first thermodynamic sweep, mo_grotz.f90:297-307 (+ Rayleigh numbers): only layer 1 is left to do unless the
   // column changed below layer 1 since the last up sweep
-  if (c.flags & COLF_DIRTY) sweep_thermo_expulsion(c, x);
-  else prologue_top_layer(c, x);
+  if (c.flags & COLF_DIRTY) sweep_thermo_expulsion<K>(c, x);
+  else prologue_top_layer<K>(c, x);
   c.flags = 0;
   if (c.status) return;
 
   int Na = c.Na;
-  const bool do_grav = (g.grav_flag == 2 && Na > 1), do_beer = (g.boundflux_flag == 2);
+  const bool do_grav = (CFG(grav_flag) == 2 && Na > 1), do_beer = (CFG(boundflux_flag) == 2);
   // The fused down sweep covers the common step.  The reference's order is kept by the unfused path whenever something
   // sits between expulsion and gravity drainage: the output block, thin-snow coupling, a possible flooding event
   // (decided from SUM(psi_g*thick) AFTER expulsion_flux: m_snow above the solid-only buoyancy is treated as possible).
   const bool coupling = (c.m_snow > 0.0 && c.thick_snow < g.thick_min);
-  const bool flood_possible = (g.flood_flag > 1 && c.m_snow > 0.0 && g.freeboard_snow_flag == 0 &&
+  const bool flood_possible = (CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
-                     !(GEN && g.testcase == 5 && c.step + 1 == 2);
+                     !(K::general && CFG(testcase) == 5 && c.step + 1 == 2);
 
   if (fused) {
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
-    testcase_scalars<GEN>(c, g, time);
-    const double beer0 = radiation_header<GEN>(c, x, time, tc);
+    testcase_scalars<K>(c, g, time);
+    const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
-    sweep_down_fused(c, x, do_beer, beer0);
+    sweep_down_fused<K>(c, x, do_beer, beer0);
     if (c.status) return;
   } else {
-    down_unfused<GEN>(c, x, col, time, tc, out_step, coupling, do_grav, do_beer);
+    down_unfused<K>(c, x, col, time, tc, out_step, coupling, do_grav, do_beer);
     if (c.status) return;
   }
 
+  // tank: the water below holds what salt the ice does not, mo_grotz.f90:573-575
+  if (K::general && CFG(tank_flag) == 2) {
+    double sS = 0.0, sm = 0.0;
+    for (int k = 1; k <= c.Na; ++k) { sS += LAY(SAMSIM_A_S_ABS, k); sm += LAY(SAMSIM_A_M, k); }
+    x.S_bu_bottom = (g.S_total - sS) / (g.m_total - sm);
+  }
+
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
-  surface_flux<GEN>(c, x);
-  sweep_up_fused(c, x, col, next_out);
+  surface_flux<K>(c, x);
+  sweep_up_fused<K>(c, x, col, next_out);
   if (c.status) return;
 
   // snow thermodynamics again, mo_grotz.f90:603-625
   const double melt_thick_snow_old = c.melt_thick_snow;
-  snow_block(c, x);
+  snow_block<K>(c, x);
   if (c.status) return;
   c.melt_thick_snow = melt_thick_snow_old + c.melt_thick_snow;
 
   // flushing preparations, mo_grotz.f90:632-664
   bool fb_valid = false;
-  if (Na > 1 && g.flush_flag > 2 && g.boundflux_flag == 2) {
-    c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), g.salt_flag, x.tf_c3);
+  if (Na > 1 && CFG(flush_flag) > 2 && (CFG(boundflux_flag) == 2 || (K::general && CFG(boundflux_flag) == 3))) {
+    // boundflux_flag 3 (:649-663) runs the same block on the air temperature instead of the surface temperature
+    const bool lab = K::general && CFG(boundflux_flag) == 3;
+    const double T_surf = lab ? c.T2m : c.T_top;
+    c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
     c.melt_thick = 0.0;
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
-    if (psi_s1 < psi_s_top_min || c.T_top >= c.T_freeze) {
-      c.freeboard = func_freeboard(c, x);
+    if (psi_s1 < psi_s_top_min || T_surf >= c.T_freeze) {
+      c.freeboard = func_freeboard<K>(c, x);
       fb_valid = true;
       if (c.freeboard > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
-        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, c.T_top, c.fl_Q1,
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, T_surf, c.fl_Q1,
                        c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
+        if (lab) c.melt_thick = dmax(c.melt_thick, 0.0);
         if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
           // sub_melt_snow, mo_functions.f90:443-474
           double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1);
@@ -1873,9 +1974,9 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
 
   // flushing, mo_grotz.f90:670-737
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
-  const bool flush_possible = ((g.flush_flag == 5 || (GEN && g.flush_flag == 4)) && Na > 2 &&
+  const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && CFG(flush_flag) == 4)) && Na > 2 &&
                                c.melt_thick + c.melt_thick_snow > 0.000000000001);
-  if (flush_possible && !fb_valid) c.freeboard = func_freeboard(c, x);
+  if (flush_possible && !fb_valid) c.freeboard = func_freeboard<K>(c, x);
   c.melt_out1 = c.melt_out1 + c.melt_thick;
   c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
   c.melt_thick = c.melt_thick + c.melt_thick_snow;
@@ -1891,15 +1992,15 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
   }
   if (flush_possible && c.freeboard > 0.001) {
     if (c.melt_thick > 0.000000000001) {
-      if (GEN && g.flush_flag == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
+      if (K::general && CFG(flush_flag) == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
         const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
         LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - c.melt_thick * rho_l * c_l * T1;
         LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (c.melt_thick * rho_l) / m1);
         LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - c.melt_thick;
         LAY(SAMSIM_A_M, 1) = m1 - c.melt_thick * rho_l;
       } else {
-        if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard(c, x);  // layer 1 changed since the last evaluation (:717)
-        flush3(c, x);
+        if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
+        flush3<K>(c, x);
         c.flags |= COLF_DIRTY;
         if (c.status) return;
       }
@@ -1911,7 +2012,7 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
     const double th1 = LAY(SAMSIM_A_THICK, 1);
     if (LAY(SAMSIM_A_PHI, Na) > psi_s_min || LAY(SAMSIM_A_PHI, Na - 1) <= psi_s_min / 2.0 || th1 / g.thick_0 > 1.5 ||
         th1 / g.thick_0 < 0.5) {
-      layer_dynamics(c, x);
+      layer_dynamics<K>(c, x);
       c.flags |= COLF_DIRTY;
       if (c.status) return;
     }
@@ -1919,13 +2020,13 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
     const int kn = (Na + 1 < N) ? Na + 1 : N;
     if (Na < N && LAY(SAMSIM_A_THICK, kn) == 0.0) {  // scrub, :772-783
       LAY(SAMSIM_A_T, Na + 1) = g.T_bottom;
-      LAY(SAMSIM_A_S_BU, Na + 1) = g.S_bu_bottom;
+      LAY(SAMSIM_A_S_BU, Na + 1) = x.S_bu_bottom;
       LAY(SAMSIM_A_PSI_L, Na + 1) = 1.0;
       LAY(SAMSIM_A_PSI_S, Na + 1) = 0.0;
     }
   } else {
     if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
-      layer_dynamics(c, x);
+      layer_dynamics<K>(c, x);
       c.flags |= COLF_DIRTY;
       if (c.status) return;
     }
@@ -1942,7 +2043,7 @@ __device__ __forceinline__ void column_step(Col &c, const Ctx &x, long long col,
 #ifndef SAMSIM_WAVES
 #define SAMSIM_WAVES 1
 #endif
-template <bool GEN>
+template <class K>
 __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel(const DevParams *__restrict__ pp, double *__restrict__ lay, double *__restrict__ scal,
                                                                         double *__restrict__ spec, int32_t *__restrict__ n_active,
                                                                         int32_t *__restrict__ status, int32_t *__restrict__ err_layer,
@@ -1961,7 +2062,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.scal = (gdouble *)scal;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
-  if (p.cfg.salt_flag == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
+  x.S_bu_bottom = (K::general && (K::fixed ? K::tank_flag : p.cfg.tank_flag) == 2) ? scal[(size_t)SAMSIM_S_S_BU_BOTTOM * (size_t)p.ncol + (size_t)col] : p.cfg.S_bu_bottom;
+  if ((K::fixed ? K::salt_flag : p.cfg.salt_flag) == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
   Col c;
@@ -2000,7 +2102,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   int n_time_out = p.n_time_out0, tc = p.time_counter0;
   long long work_done = 0;
   for (long long s = 0; s < p.nsteps; ++s) {
-    if (p.cfg.atmoflux_flag == 2) {
+    if ((K::fixed ? K::atmoflux_flag : p.cfg.atmoflux_flag) == 2) {
       if (time > time_input(tc)) tc = tc + 1;
       if (tc > p.flen) tc = p.flen;
     }
@@ -2010,7 +2112,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
-      column_step<GEN>(c, x, col, time, tc, out_step, next_out);
+      column_step<K>(c, x, col, time, tc, out_step, next_out);
     }
     time = time + p.cfg.dt;
     step = step + 1;
@@ -2036,8 +2138,9 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SSTORE(energy_stored, SAMSIM_S_ENERGY_STORED); SSTORE(freshwater, SAMSIM_S_FRESHWATER); SSTORE(total_resist, SAMSIM_S_TOTAL_RESIST);
   SSTORE(thickness, SAMSIM_S_THICKNESS); SSTORE(bulk_salin, SAMSIM_S_BULK_SALIN);
 #undef SSTORE
+  sc[(size_t)SAMSIM_S_S_BU_BOTTOM * nc] = x.S_bu_bottom;
   // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112
-  if (p.cfg.boundflux_flag == 2 && (!GEN || p.cfg.atmoflux_flag == 2)) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
+  if ((K::fixed ? K::boundflux_flag : p.cfg.boundflux_flag) == 2 && (!K::general || (K::fixed ? K::atmoflux_flag : p.cfg.atmoflux_flag) == 2)) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
 }
 
 }  // namespace
@@ -2047,9 +2150,8 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
-  const bool general = (g.boundflux_flag == 2 && g.atmoflux_flag != 2) || g.grav_flag == 3 || g.flush_flag == 4 ||
-                       g.flood_flag == 3 || g.testcase == 3 || g.testcase == 5;
-  auto kernel = general ? samsim_step_kernel<true> : samsim_step_kernel<false>;
+  auto kernel = flags_match<KSheba>(g) ? samsim_step_kernel<KSheba>
+                : flags_match<KPlate>(g) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
                      hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active);

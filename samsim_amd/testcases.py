@@ -1,6 +1,5 @@
 """Host-side mirror of the reference's per-testcase setup `init(testcase)` (mo_init.f90:73-2034) for the
-testcases in scope (1, 3, 4, 5, 7: every shipped testcase that runs on boundflux_flag 1/2 without the tank and
-lab options) plus the synthetic BASELINE configurations.
+testcases in scope (1-7 and 9: every shipped testcase that runs without bgc tracers and lab snow) plus the synthetic BASELINE configurations.
 
 `init` in the reference fills the `mo_data` globals; here it returns the POD `Config` that crosses the C-ABI
 and the SoA initial `State`.  Defaults follow mo_init.f90:83-132, the common tail mo_init.f90:1981-2031.
@@ -54,6 +53,7 @@ def _blank_state(c: Config, ncol: int) -> State:
     st.arr("S_bu")[:] = c.S_bu_bottom
     st.arr("psi_l")[:] = 1.0
     st.sc("precip_scale")[:] = 1.0
+    st.sc("S_bu_bottom")[:] = c.S_bu_bottom
     return st
 
 
@@ -93,6 +93,51 @@ def testcase4(ncol: int = 1, nlayer: int = 100, n_top: int = 20, n_bottom: int =
     st.arr("S_abs")[:] = c.S_bu_bottom * st.arr("m")
     st.arr("H_abs")[:] = 0.0
     return c, st
+
+
+def _tank(testcase, ncol, nlayer, n_top, n_bottom, tank_depth, alpha_stable, fl_q_bottom, T2m, T_top, T_bottom, S_bu_bottom,
+          thick_0, dt, time_out, n_out):
+    """the tank experiments (testcases 2, 6, 9): air temperature T2m over a tank of finite depth, boundflux_flag 3,
+    tank_flag 2 (the salt the ice rejects raises the salinity of the water below)"""
+    c = default_config()
+    c.testcase = testcase
+    c.nlayer, c.n_top, c.n_bottom = nlayer, n_top, n_bottom
+    c.tank_flag, c.boundflux_flag, c.grav_heat_flag = 2, 3, 1
+    c.alpha_flux_instable, c.alpha_flux_stable = 22.0, alpha_stable
+    c.T_bottom, c.S_bu_bottom = T_bottom, S_bu_bottom
+    c.thick_0, c.dt, c.time_out = thick_0, dt, time_out
+    c.time_total = n_out
+    c.m_total = RHO_L * tank_depth
+    c.S_total = RHO_L * S_bu_bottom * tank_depth
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.sc("fl_q_bottom")[:] = fl_q_bottom
+    st.sc("T2m")[:] = T2m
+    st.sc("T_top")[:] = T_top
+    st.sc("S_bu_bottom")[:] = S_bu_bottom
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[:] = st.arr("thick") * RHO_L
+    st.arr("S_abs")[:] = c.S_bu_bottom * st.arr("m")
+    st.arr("H_abs")[:] = st.arr("m") * c.T_bottom          # (sic: no c_l, mo_init.f90:1002)
+    return c, st
+
+
+def testcase2(ncol: int = 1):
+    """mo_init.f90:948-1003: 1 m tank, T2m -20 C, warming after 15 and 25 days (sub_test2); bgc off"""
+    return _tank(2, ncol, 100, 3, 10, 1.0, 15.0, 10.0, -20.0, -18.0, 0.0, 31.2, 0.01, 30.0, 3600.0 * 6.0,
+                 3600.0 * 6.0 * 4.0 * 30.0)
+
+
+def testcase6(ncol: int = 1):
+    """mo_init.f90:1278-1330: 15.9 cm tank, thick_0 2.5 mm, dt 0.5 s, T2m switching between -18 and -5 C (sub_test6)"""
+    return _tank(6, ncol, 40, 3, 3, 0.159, 11.0, 35.0, -18.0, -18.0, 0.0, 31.2, 0.0025, 0.5, 1800.0 / 2.0,
+                 1800.0 / 2.0 * 39.0 * 2.0 * 2.0)
+
+
+def testcase9(ncol: int = 1):
+    """mo_init.f90:1684-1740: 0.8 m tank, freeze at -15 C for three days, then melt at +1 C (sub_test9)"""
+    return _tank(9, ncol, 100, 3, 10, 0.8, 15.0, 10.0, -15.0, -10.0, -0.07, 34.6, 0.005, 10.0, 3600.0 * 2.0,
+                 3600.0 * 2.0 * 12.0 * 6.0)
 
 
 def testcase3(ncol: int = 1):

@@ -16,6 +16,8 @@ Fixtures are DATA only -- inputs and expected outputs:
   func_golden.npz           function-level vectors from the reference modules (oracle/ref_hook/func_harness.f90)
   tc3_ref_fullprec.npz      testcase 3 (Notz fluxes + constant snow fall), all 216 output points
   tc5_ref_fullprec.npz      testcase 5 (fixed fluxes, flushing of a 1 m slab), scalars at all 240 output points, layers at every 6th
+  tc{2,6,9}_ref_fullprec.npz  the tank experiments (boundflux_flag 3, tank_flag 2; bgc off): scalars (incl. the evolving
+                            S_bu_bottom) at all output points, layers at every 4th
   tc7_ref_fullprec.npz      testcase 7 (SHEBA with the simple parametrisations): scalars of the first 131 output points (the
                             reference's fl_grav_drain_simple reads an uninitialised local, so its own trajectory depends on
                             stack history), layers at selected ones, and teacher-forcing pairs through the first
@@ -136,6 +138,14 @@ def main():
     for k, v in pack(recs, with_layers=False).items():
         d["all_" + k] = v
     np.savez_compressed(os.path.join(OUT, "tc5_ref_fullprec.npz"), **d)
+    # --- testcases 2 / 6 / 9 (tank experiments, bgc off): all output points, layers at every 4th
+    for tc in (2, 6, 9):
+        recs = cached(tc, f"tc{tc}_dump.bin", {"SAMSIM_REF_BGC": "0"})
+        d = pack(recs[3::4])
+        d["index"] = np.arange(len(recs))[3::4]
+        for k, v in pack(recs, with_layers=False).items():
+            d["all_" + k] = v
+        np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
     recs = cached(7, "tc7_dump.bin", {"SAMSIM_REF_MAXSTEPS": "6000000"})
     sel = [0, 1, 2, 10, 40, 80, 120, 130]
     d = pack([recs[i] for i in sel])

@@ -91,3 +91,19 @@ def test_fortran_host_testcases_3_and_5(tmp_path):
         if i < T.shape[0]:
             na = int(ref["all_N_active"][i])
             assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc5 output {i}"
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")
+def test_fortran_host_tank_experiment(tmp_path):
+    """init(9) in the Fortran host (boundflux_flag 3, tank_flag 2, m_total / S_total from the tank depth): printed
+    temperature profiles against the reference's records of the same output points"""
+    out = run_host(tmp_path, "&samsim_run testcase=9, ncol=8 /\n")
+    assert "SAMSIM is finished" in out
+    ref = golden("tc9_ref_fullprec.npz")
+    T = load(tmp_path, "T")
+    assert T.shape == (72, 100)
+    for j, i in enumerate(ref["index"]):
+        na = int(ref["all_N_active"][i])
+        assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc9 output {i}"
+    s = (tmp_path / "output" / "dat_settings.dat").read_text()
+    assert "tank_flag               2" in s and "boundflux_flag          3" in s

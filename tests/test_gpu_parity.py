@@ -216,11 +216,12 @@ def test_failed_columns_are_frozen_and_reported():
 
 
 def test_unsupported_flags_are_rejected():
-    cfg, _ = tcs.testcase1(1)
-    cfg.boundflux_flag = 3
-    with pytest.raises(samsim_amd.SamsimError) as e:
-        samsim_amd.hip_solver(cfg, 4)
-    assert e.value.code == -2
+    for flag, value in (("prescribe_flag", 2), ("flush_flag", 6), ("bgc_flag", 2), ("lab_snow_flag", 1)):
+        cfg, _ = tcs.testcase2(1) if flag == "lab_snow_flag" else tcs.testcase1(1)
+        setattr(cfg, flag, value)
+        with pytest.raises(samsim_amd.SamsimError) as e:
+            samsim_amd.hip_solver(cfg, 4)
+        assert e.value.code == -2, flag
     cfg, _ = tcs.testcase1(1)
     cfg.struct_size = 8
     with pytest.raises(samsim_amd.SamsimError) as e:

@@ -136,6 +136,30 @@ def test_tc7_simple_parametrisations_free_run_and_reference_windows():
         _check(g, o, f"tc7 window {idx}")
 
 
+@pytest.mark.parametrize("tc,nout", [(2, 120), (9, 72), (6, 60)])
+def test_tank_experiments(tc, nout):
+    """testcases 2, 6, 9 (boundflux_flag 3, tank_flag 2, T2m schedules): the HIP path's output snapshots against the
+    reference's own records and, at the end, the full state against the oracle; the water below the ice gets saltier"""
+    ncol = 8
+    cfg, st = getattr(tcs, f"testcase{tc}")(ncol)
+    g, o = _pair(cfg, ncol, st)
+    ref = golden(f"tc{tc}_ref_fullprec.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    g.set_output_window(3, 1)
+    for i in range(nout):
+        out = g.run_to_output()
+        assert out.step == ref["all_step"][i] and out.n_active[0] == ref["all_N_active"][i], f"tc{tc} output {i}"
+        for n, floor in (("S_bu_bottom", 1e-7), ("thickness", 1e-6), ("bulk_salin", 1e-5), ("T_top", 1e-2), ("freeboard", 1e-6)):
+            assert rel_err(out.sc(n)[0], ref["all_s_" + n][i], floor) <= 2e-6, f"tc{tc} output {i}: {n} vs reference"
+        if i in rows:
+            na = int(out.n_active[0])
+            for n in ["T", "psi_s", "psi_l", "S_bu", "thick"]:
+                assert rel_err(out.arr(n)[:na, 0], ref["a_" + n][rows[i], :na], 1e-6) <= 2e-6, f"tc{tc} output {i}: {n}"
+    o.step(g.get_clock().step)
+    sg, so = _check(g, o, f"tc{tc} end of run", rtol=2e-6)
+    assert so.sc("S_bu_bottom")[0] > cfg.S_bu_bottom and (sg.lay == sg.lay[:, :, :1]).all()
+
+
 def test_flood_simple_under_heavy_snow():
     """flood_flag 3 never fires in the reference's own testcase-7 run (the freeboard stays above -5 cm), so it is driven
     here: a winter state of that run is loaded with 1.3 m of cold snow, which pushes the freeboard below neg_free and

@@ -200,6 +200,24 @@ def test_tc5_fixed_flux_flushing_bitwise():
     assert not o.get_status()[0].any()
 
 
+@pytest.mark.parametrize("tc,nout", [(2, 120), (6, 156), (9, 72)])
+def test_tank_experiments_bitwise(tc, nout):
+    """testcases 2, 6, 9 (boundflux_flag 3: air temperature over a tank; tank_flag 2: S_bu_bottom from the salt budget;
+    sub_test2/6/9 temperature schedules; freeze and melt), bgc off: every output point of the full runs, bit for bit"""
+    cfg, st = getattr(tcs, f"testcase{tc}")(1)
+    o = oracle_solver(cfg, 1)
+    o.set_state(st)
+    o.set_clock()
+    ref = golden(f"tc{tc}_ref_fullprec.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    assert len(ref["all_step"]) == nout
+    for i in range(nout):
+        out = o.run_to_output()
+        _compare_output(out, ref, i, rows.get(i), f"tc{tc} output {i}")
+        assert out.sc("S_bu_bottom")[0] == ref["all_s_S_bu_bottom"][i], f"tc{tc} output {i}: S_bu_bottom"
+    assert ref["all_s_S_bu_bottom"].max() > cfg.S_bu_bottom + 0.2 and not o.get_status()[0].any()
+
+
 def test_tc7_simple_parametrisations():
     """testcase 7 (albedo 1, grav_flag 3, flush_flag 4, flood_flag 3 on SHEBA forcing).  The reference's
     fl_grav_drain_simple accumulates into a local it never initialises (mo_grav_drain.f90:226,246-248), so the reference's
