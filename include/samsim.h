@@ -167,7 +167,8 @@ int samsim_set_output_window(samsim_handle *h, int64_t col0, int64_t ncols);
 /* output (mo_output.f90:116-146): latest snapshot; returns SAMSIM_ERR_NO_OUTPUT if none was taken */
 int samsim_get_output(samsim_handle *h, samsim_output_soa *o);
 
-/* the reference's STOP codes: status[c] = 0 or code; step/layer of first failure */
+/* the reference's STOP codes: status[c] = 0 or code; step/layer of first failure.
+ * 9001 is the library's own: an internal hand-over assumption of the fused sweeps did not hold for this column. */
 int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t *layer);
 /* sum over columns of N_active accumulated over all steps taken (layer-cell updates) */
 int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);

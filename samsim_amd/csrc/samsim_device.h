@@ -13,7 +13,9 @@
 
 // device-internal layer arrays: the public ones (enum samsim_layer_array) followed by scratch
 enum dev_layer_array {
-  D_V_EX = SAMSIM_NARR,   // scratch row: equivalent resistance R(k) of flush3 (mo_flush.f90:137-145)
+  D_V_EX = SAMSIM_NARR,   // scratch row: equivalent resistance R(k) of flush3 (mo_flush.f90:137-145), after the up sweep;
+                          // before it, D_HR = the half resistance thick/(2k) the down sweep hands to the up sweep
+  D_HR = D_V_EX,
   DEV_NARR
 };
 

@@ -138,6 +138,7 @@ struct Col {
   double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
   double psi_l_top;  // psi_l(1) of this step's Expulsion (the albedo reads it before the down sweep stores the psi arrays)
+  bool psi_full;     // this step's down sweep stored psi_s / psi_l / psi_g for every layer (not only for layer 1)
 };
 
 // Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
@@ -701,6 +702,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
     LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
     LAY(SAMSIM_A_PSI_G, k) = psi_g;
+    if (k >= 2) LAY(D_HR, k) = thick / (2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));  // hand-over to the up sweep
     const double m_in = m;
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
@@ -1016,7 +1018,7 @@ __device__ RARE void sweep_beer(Col &c, double beer0) {
 // j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
 // T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
 template <class K>
-__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0) {
+__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0, bool store_psi) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -1065,9 +1067,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
     }
     if (psi_g > 0.0) buoy_g += psi_g * thick;
-    LAY(SAMSIM_A_PSI_S, j) = ex.psi_s;
-    LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
-    LAY(SAMSIM_A_PSI_G, j) = psi_g;
+    // The up sweep only needs the layer's half resistance thick/(2k) (sub_fl_Q, mo_thermo_functions.f90:201-223); the three
+    // volume fractions are stored when something reads them this step (see column_step), and always for layer 1
+    if (store_psi || j == 1) {
+      LAY(SAMSIM_A_PSI_S, j) = ex.psi_s;
+      LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
+      LAY(SAMSIM_A_PSI_G, j) = psi_g;
+    }
+    if (j >= 2) LAY(D_HR, j) = thick / (2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
     m = m + flm_next - flm_j;
     if (flm_next < 0.0) {
       H_abs = H_abs + flm_next * T * c_l;
@@ -1187,6 +1194,25 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
   return pen * (1.0 - c.albedo) * c.fl_sw;
 }
 
+// twice-iterated linearised radiative balance for the surface temperature, mo_heat_fluxes.f90:115-148: a function of the
+// forcing, the albedo, and the temperature of the snow (or of the top layer under thin / no snow)
+__device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, double T1, double thick_min) {
+  double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
+  const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
+  const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
+  T_old = T_old + zeroK;
+  double temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
+  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 - zeroK;
+  T_old = temp1 + zeroK;
+  temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
+  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 - zeroK;
+  return temp1;
+}
+
 template <class K>
 __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
@@ -1213,20 +1239,10 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
   const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
-  double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
-  T_old = T_old + zeroK;
-  double temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
-  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
-  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
-  temp1 = temp1 - zeroK;
-  T_old = temp1 + zeroK;
-  temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
-  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
-  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
-  temp1 = temp1 - zeroK;
-  c.T_top = temp1;
+  double temp1;
+  c.T_top = radiative_T_top(c, fl_rest, T1, thick_min);
 
   if (c.thick_snow >= thick_min / 100.0) c.T_freeze = 0.0;
   else c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
@@ -1287,8 +1303,11 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   // layer k (old values)
   double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  // (the reference adds psi_g*0._wp to the conductivity, mo_thermo_functions.f90:213: a no-op for finite psi_g)
-  double hr_k = th_k / (2.0 * (LAY(SAMSIM_A_PSI_S, Na) * k_s + LAY(SAMSIM_A_PSI_L, Na) * k_l));  // half resistance of layer k: the same quotient serves fl_Q(k+1) and fl_Q(k)
+  // half resistance thick/(2k) of layer k, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp, mo_thermo_functions.f90:213:
+  // a no-op for finite psi_g): the same quotient serves fl_Q(k+1) and fl_Q(k).  Layers >= 2 take it from the down sweep;
+  // layer 1 forms it here, because flooding and snow-ice formation change thick(1) between the two sweeps.
+  const double hr_top = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
+  double hr_k = (Na >= 2) ? LAY(D_HR, Na) : hr_top;
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
@@ -1296,7 +1315,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
-      hr_u = th_u / (2.0 * (LAY(SAMSIM_A_PSI_S, k - 1) * k_s + LAY(SAMSIM_A_PSI_L, k - 1) * k_l));
+      hr_u = (k > 2) ? LAY(D_HR, k - 1) : hr_top;
       const double R = hr_u + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
@@ -1844,7 +1863,8 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
 
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
 template <class K>
-__device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, double time, int tc, bool out_step, bool next_out) {
+__device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, double time, int tc, bool out_step, bool next_out,
+                                            bool last_step) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N;
 
@@ -1900,9 +1920,26 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     testcase_scalars<K>(c, g, time);
     const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
-    sweep_down_fused<K>(c, x, do_beer, beer0);
+    // Who reads the psi_s / psi_l / psi_g arrays this sweep would store?  The vital signs at the next output point, a
+    // get_state after the launch, and -- when the surface melts or the snow releases melt water -- func_freeboard and
+    // flush3 (mo_grotz.f90:636,670,717-725).  Whether those run is decided after the sweep; it is predicted here with
+    // wide margins (surface within 1 K of melting, top layer within 0.05 of the solid-fraction threshold, snow warmer
+    // than -8 C or already wet) and the late readers stop the column (code 9001) should the prediction ever have been
+    // wrong.  Everything else (layer 1 itself, the up sweep's conductivities) is handed over separately.
+    bool store_psi = true;
+    if (K::fixed && K::boundflux_flag == 2 && K::flush_flag == 5) {
+      const double th1 = LAY(SAMSIM_A_THICK, 1), m1 = LAY(SAMSIM_A_M, 1);
+      const Expelled e1 = expulsion(LAY(SAMSIM_A_PHI, 1), th1, m1);
+      const double T_fr = (c.thick_snow >= g.thick_min / 100.0) ? 0.0 : func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / m1, CFG(salt_flag), x.tf_c3);
+      const double T_top_est = radiative_T_top(c, c.fl_lw + 0.0 + 0.0, LAY(SAMSIM_A_T, 1), g.thick_min);
+      store_psi = next_out || last_step || e1.psi_s < psi_s_top_min + 0.05 || T_top_est >= T_fr - 1.0 ||
+                  (c.thick_snow > 0.0 && (c.T_snow > -8.0 || c.melt_thick_snow > 0.0));
+    }
+    c.psi_full = store_psi;
+    sweep_down_fused<K>(c, x, do_beer, beer0, store_psi);
     if (c.status) return;
   } else {
+    c.psi_full = true;
     down_unfused<K>(c, x, col, time, tc, out_step, coupling, do_grav, do_beer);
     if (c.status) return;
   }
@@ -1936,6 +1973,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || T_surf >= c.T_freeze) {
+      if (!c.psi_full) STOPC(9001, 0);
       c.freeboard = func_freeboard<K>(c, x);
       fb_valid = true;
       if (c.freeboard > 0.0000000000001) {
@@ -1976,6 +2014,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && CFG(flush_flag) == 4)) && Na > 2 &&
                                c.melt_thick + c.melt_thick_snow > 0.000000000001);
+  if (flush_possible && !c.psi_full) STOPC(9001, 0);
   if (flush_possible && !fb_valid) c.freeboard = func_freeboard<K>(c, x);
   c.melt_out1 = c.melt_out1 + c.melt_thick;
   c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
@@ -2112,7 +2151,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
-      column_step<K>(c, x, col, time, tc, out_step, next_out);
+      column_step<K>(c, x, col, time, tc, out_step, next_out, s + 1 == p.nsteps);
     }
     time = time + p.cfg.dt;
     step = step + 1;
