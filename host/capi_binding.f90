@@ -121,6 +121,24 @@ MODULE mo_samsim_capi
        INTEGER(c_int64_t), INTENT(out) :: step(*)
        INTEGER(c_int32_t), INTENT(out) :: layer(*)
      END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_tracers(h, n_bgc, bgc_bottom, bgc_total) BIND(C, name='samsim_set_tracers')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       INTEGER(c_int32_t), VALUE :: n_bgc
+       REAL(c_double), INTENT(in) :: bgc_bottom(*)
+       TYPE(c_ptr), VALUE :: bgc_total                    ! [n_bgc] with tank_flag 2, else c_null_ptr
+     END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_tracer_state(h, bgc_abs, col0, ncols) BIND(C, name='samsim_set_tracer_state')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       REAL(c_double), INTENT(in) :: bgc_abs(*)           ! (ncols, nlayer, n_bgc), column fastest
+       INTEGER(c_int64_t), VALUE :: col0, ncols
+     END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_get_tracer_output(h, bgc_abs, bgc_bottom) BIND(C, name='samsim_get_tracer_output')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       REAL(c_double), INTENT(out) :: bgc_abs(*), bgc_bottom(*)
+     END FUNCTION
      INTEGER(c_int) FUNCTION samsim_get_ensemble_stats(h, nslots, slots, out) BIND(C, name='samsim_get_ensemble_stats')
        IMPORT
        TYPE(c_ptr), VALUE :: h

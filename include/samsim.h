@@ -59,7 +59,7 @@ typedef struct samsim_config {
   int32_t freeboard_snow_flag;  /* 0, 1                                                              */
   int32_t snow_flush_flag;      /* 0, 1                                                              */
   int32_t snow_precip_flag;     /* (echo only)                                                       */
-  int32_t bgc_flag;             /* 1 (tracers are out of scope: SURVEY.md section 8 f.2)             */
+  int32_t bgc_flag;             /* 1 none, 2 passive tracers advected with the brine (samsim_set_tracers)  */
   int32_t i_time_out;           /* INT(time_out/dt), mo_init.f90:2001                                */
   double  dt, thick_0, thick_min;            /* thick_min = thick_0/2, mo_init.f90:1994              */
   double  T_bottom, S_bu_bottom;
@@ -172,6 +172,18 @@ int samsim_get_output(samsim_handle *h, samsim_output_soa *o);
 int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t *layer);
 /* sum over columns of N_active accumulated over all steps taken (layer-cell updates) */
 int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
+
+/* Passive biogeochemical tracers (bgc_flag 2; mo_data.f90:181-193, bgc_advection mo_mass.f90:150-209): n_bgc tracers,
+ * bgc_abs[t][k][c] = amount of tracer t in layer k of column c.  samsim_set_tracers fixes their number, the concentration
+ * of the water below the ice (bgc_bottom, mo_init.f90:934-935) and -- tank_flag 2 only, else NULL -- the totals in the tank
+ * (bgc_total, mo_init.f90:1013); it must be called before the first step.  The tracer state is zero until set
+ * (init: bgc_abs(1,:) = bgc_bottom(:)*m(1), mo_init.f90:940).  samsim_get_tracer_output returns the snapshot taken at the
+ * reference's output point for the output window: bgc_abs[n_bgc][nlayer][ncols], bgc_bottom[n_bgc][ncols]. */
+#define SAMSIM_MAX_NBGC 8
+int samsim_set_tracers(samsim_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total);
+int samsim_set_tracer_state(samsim_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols);
+int samsim_get_tracer_state(samsim_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols);
+int samsim_get_tracer_output(samsim_handle *h, double *bgc_abs, double *bgc_bottom);
 
 /* Ensemble statistics (what replaces "one column per .dat row", mo_output.f90:129-144, when the
  * run holds 10^5..10^6 columns): for each requested per-column scalar (enum samsim_scalar, or SAMSIM_STAT_N_ACTIVE) the

@@ -29,6 +29,7 @@ MODULE mo_output
   INTEGER, PARAMETER :: dump_unit = 77
   INTEGER, PARAMETER :: nscal = 48
   INTEGER, SAVE      :: trace_from = 0, trace_to = -1
+  LOGICAL, SAVE      :: bgc_open = .FALSE.
   LOGICAL, SAVE      :: quiet = .FALSE.
 
 CONTAINS
@@ -141,12 +142,26 @@ CONTAINS
     CALL dump_record(1)
   END SUBROUTINE output
 
+  !> tracer records go to a second stream file, <dump>.bgc: int32 step, N_active, N_bgc, Nlayer; bgc_bottom(N_bgc); bgc_abs(Nlayer,N_bgc)
   SUBROUTINE output_bgc(Nlayer,N_active,bgc_bottom,N_bgc,bgc_abs,psi_l,thick,m,format_bgc)
+    USE mo_data, ONLY: i
     INTEGER,                             INTENT(in) :: Nlayer, N_bgc, N_active
     REAL(wp), DIMENSION(N_bgc),          INTENT(in) :: bgc_bottom
     REAL(wp), DIMENSION(Nlayer),         INTENT(in) :: psi_l,m,thick
     REAL(wp), DIMENSION(Nlayer,N_bgc),   INTENT(in) :: bgc_abs
     CHARACTER*12000,                     INTENT(in) :: format_bgc
+    CHARACTER(len=1024) :: path
+    INTEGER :: stat, length
+    IF (quiet) RETURN
+    IF (.NOT. bgc_open) THEN
+       CALL GET_ENVIRONMENT_VARIABLE('SAMSIM_REF_DUMP', path, length, stat)
+       IF (stat /= 0 .OR. length == 0) path = './ref_dump.bin'
+       OPEN(dump_unit + 1, file=TRIM(path)//'.bgc', STATUS='replace', ACCESS='stream', FORM='unformatted')
+       bgc_open = .TRUE.
+    END IF
+    WRITE(dump_unit + 1) i, N_active, N_bgc, Nlayer
+    WRITE(dump_unit + 1) bgc_bottom
+    WRITE(dump_unit + 1) bgc_abs
   END SUBROUTINE output_bgc
 
   SUBROUTINE output_raw(Nlayer,N_active,time,T,thick,S_bu,psi_s,psi_l,psi_g)
@@ -170,7 +185,7 @@ CONTAINS
 
   SUBROUTINE output_begin(Nlayer,debug_flag,format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                           &format_melt)
-    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag
+    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag, i_time_out
     INTEGER,         INTENT(in)  :: Nlayer,debug_flag
     CHARACTER*12000, INTENT(out) :: format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                                     &format_melt
@@ -183,6 +198,8 @@ CONTAINS
     quiet = found .AND. v == 1
     CALL env_int('SAMSIM_REF_MAXSTEPS', v, found)
     IF (found .AND. v > 0) i_time = MIN(i_time, v)
+    CALL env_int('SAMSIM_REF_I_TIME_OUT', v, found)      ! output cadence in steps (diagnosis of a first difference)
+    IF (found .AND. v > 0) i_time_out = v
     CALL env_int('SAMSIM_REF_BGC', v, found)
     IF (found .AND. v == 0) bgc_flag = 1
     CALL env_int('SAMSIM_REF_TRACE_FROM', v, found)

@@ -56,6 +56,14 @@ typedef struct column {
   double energy_stored, freshwater, total_resist, thickness, bulk_salin;
   double dT2m, precip_scale;
   double S_bu_bottom;            /* salinity of the water below the ice: cfg value, or the tank budget (tank_flag 2) */
+  /* passive tracers, mo_data.f90:181-193 */
+  int n_bgc;
+  double *bgc[SAMSIM_MAX_NBGC];  /* bgc_abs(:, t), 1-based */
+  double bgc_bottom[SAMSIM_MAX_NBGC];
+  const double *bgc_total;       /* tank totals (shared) */
+  double *flb;                   /* fl_brine_bgc(N+1, N+1): FLB(i, j) = brine from layer i to layer j this step */
+  double *snap_bgc;              /* [n_bgc][N] */
+  double snap_bgc_bottom[SAMSIM_MAX_NBGC];
   /* clock */
   double time;
   int64_t step;                  /* completed steps; i = step+1 */
@@ -73,6 +81,7 @@ typedef struct column {
   double snap_scal[SAMSIM_NSCAL];
 } column;
 
+#define FLB(i, j) c->flb[(size_t)(i) * (size_t)(c->N + 2) + (size_t)(j)]
 #define STOP(code, layer) do { if (!c->status) { c->status = (code); c->err_step = c->step + 1; c->err_layer = (layer); } return; } while (0)
 #define CHECK() do { if (c->status) return; } while (0)
 
@@ -290,9 +299,10 @@ static void sub_test6(double time, double *T2m) {
 }
 
 /* sub_turb_flux, mo_functions.f90:347-363 */
-static void sub_turb_flux(double T_bottom, double S_bu_bottom, double T, double *S_abs, double m, double dt) {
+static double sub_turb_flux(double T_bottom, double S_bu_bottom, double T, double *S_abs, double m, double dt) {
   double turb = Turb_A * exp(Turb_B * (-oracle_func_density(T_bottom, S_bu_bottom) + oracle_func_density(T, *S_abs / m))) * dt;
   *S_abs = *S_abs - turb * (*S_abs / m - S_bu_bottom);
+  return turb;   /* the tracers of the bottom layer mix with the same coefficient, :358-360 */
 }
 
 /* sub_melt_thick, mo_functions.f90:386-428 */
@@ -457,6 +467,10 @@ static void fl_grav_drain(column *c) {
   for (k = 1; k <= N + 1; k++) fl_m[k] = 0.0;  /* local fl_m is uninitialised beyond N_active+1 in the reference; unused */
   fl_m[1] = 0.0;
   for (k = 1; k <= Na; k++) fl_m[k + 1] = fl_up[k];
+  if (c->n_bgc > 0) {                                                                /* :178-185 (sic: column N_active is read) */
+    for (k = 1; k <= Na - 1; k++) FLB(k, Na + 1) = FLB(k, Na) + fl_down[k];
+    for (k = 1; k <= Na; k++) FLB(k + 1, k) = FLB(k + 1, k) + fl_up[k];
+  }
 
   mass_transfer(c, fl_m);                                                            /* :187 */
 
@@ -766,6 +780,10 @@ static void flood(column *c) {
     c->m_snow = c->m_snow - shift / c->thick_snow * c->m_snow;
     c->thick_snow = c->thick_snow - shift;
   }
+  if (c->n_bgc > 0) {                                                                /* :140-143 */
+    FLB(Na, 1) = FLB(Na, 1) + flood_brine;
+    FLB(Na + 1, Na) = FLB(Na + 1, Na) + flood_brine;
+  }
 }
 
 /* flood_simple, mo_flood.f90:167-210 (flood_flag 3) */
@@ -844,6 +862,14 @@ static void flush3(column *c) {
   }
   flush_v[Na] = flush_v[Na - 1];
   flush_h[Na] = 0.0;
+
+  if (c->n_bgc > 0) {                                                                /* :168-175 */
+    double sh = 0.0;
+    for (k = 1; k <= Na - 1; k++) FLB(k, Na) = FLB(k, Na) + flush_h[k];
+    for (k = 1; k <= N; k++) sh += flush_h[k];
+    FLB(Na, Na + 1) = FLB(Na, Na + 1) + sh;
+    for (k = 1; k <= Na; k++) FLB(k, k + 1) = FLB(k, k + 1) + flush_v[k];
+  }
 
   fl_m[1] = 0.0;
   for (k = 1; k <= Na; k++) fl_m[k + 1] = -flush_v[k];
@@ -1044,6 +1070,56 @@ static void top_grow(column *c) {
   c->N_active = Na;
 }
 
+/* bgc_advection, mo_mass.f90:150-209: upwind advection of the tracers with the brine fluxes of this step, every flux limited
+ * to a third of the layer's content; the (N+1)^2 loop of the reference as written */
+static void bgc_advection(column *c) {
+  int N = c->N, Na = c->N_active, i, j, t;
+  double bgc_temp[SAMSIM_MAX_NLAYER + 2], bgc_br[SAMSIM_MAX_NLAYER + 2], flux;
+  for (t = 0; t < c->n_bgc; t++) {
+    double *q = c->bgc[t];
+    for (i = 1; i <= N; i++) bgc_temp[i] = q[i];
+    for (i = 1; i <= Na; i++) bgc_br[i] = q[i] / dmax(c->psi_l[i] * c->thick[i] * rho_l, 0.000000000000001);
+    for (i = 1; i <= Na; i++) {
+      for (j = 1; j <= Na; j++) {
+        flux = dmin(FLB(i, j) * bgc_br[i], q[i] / 3.0);
+        bgc_temp[i] = bgc_temp[i] - flux;
+        bgc_temp[j] = bgc_temp[j] + flux;
+      }
+    }
+    for (i = 1; i <= Na; i++) {
+      flux = dmin(FLB(i, Na + 1) * bgc_br[i], q[i] / 3.0);
+      bgc_temp[i] = bgc_temp[i] - flux;
+    }
+    for (j = 1; j <= Na; j++) {
+      flux = FLB(Na + 1, j) * c->bgc_bottom[t];
+      bgc_temp[j] = bgc_temp[j] + flux;
+    }
+    for (i = 1; i <= N; i++) q[i] = bgc_temp[i];
+  }
+  for (i = 0; i < (N + 2) * (N + 2); i++) c->flb[i] = 0.0;                           /* mo_grotz.f90:745 */
+}
+
+/* One regrid routine, tracers included.  In the reference every statement on S_abs / S_bu / S_bu_bottom has a twin on
+ * bgc_temp / bgc_bulk / bgc_bottom (mo_layer_dynamics.f90:205-373); the twin is obtained here by running the same
+ * routine on a scratch copy of the column in which the tracer stands in for S_abs. */
+static void regrid(column *c, void (*fn)(column *)) {
+  int N = c->N, k, t;
+  if (c->n_bgc == 0) { fn(c); return; }
+  double m0[SAMSIM_MAX_NLAYER + 3], th0[SAMSIM_MAX_NLAYER + 3], H0[SAMSIM_MAX_NLAYER + 3];
+  double m2[SAMSIM_MAX_NLAYER + 3], th2[SAMSIM_MAX_NLAYER + 3], H2[SAMSIM_MAX_NLAYER + 3], q2[SAMSIM_MAX_NLAYER + 3];
+  int Na0 = c->N_active;
+  for (k = 0; k <= N + 2; k++) { m0[k] = c->m[k]; th0[k] = c->thick[k]; H0[k] = c->H_abs[k]; }
+  fn(c);
+  for (t = 0; t < c->n_bgc; t++) {
+    column cc = *c;
+    for (k = 0; k <= N + 2; k++) { m2[k] = m0[k]; th2[k] = th0[k]; H2[k] = H0[k]; q2[k] = c->bgc[t][k]; }
+    cc.m = m2; cc.thick = th2; cc.H_abs = H2; cc.S_abs = q2;
+    cc.N_active = Na0; cc.S_bu_bottom = c->bgc_bottom[t]; cc.status = 0;
+    fn(&cc);
+    for (k = 0; k <= N + 2; k++) c->bgc[t][k] = q2[k];
+  }
+}
+
 /* layer_dynamics, mo_layer_dynamics.f90:64-175: exactly one branch per call */
 static void layer_dynamics(column *c) {
   const samsim_config *g = c->cfg;
@@ -1051,22 +1127,22 @@ static void layer_dynamics(column *c) {
   double *phi = c->phi, *thick = c->thick, thick_0 = g->thick_0;
   int km1 = (Na - 1 > 1) ? Na - 1 : 1;
   if (phi[N - 1] <= psi_s_min / 2.0 && phi[Na] < 0.00001 && Na == N && thick[N_top + 1] / thick_0 > 1.000001 && bf == 1) {
-    bottom_melt(c);
+    regrid(c, bottom_melt);
   } else if (Na > 1 && Na < N && phi[Na] < 0.00001 && phi[km1] <= psi_s_min / 2.0 && bf == 1) {
-    bottom_melt_simple(c);
+    regrid(c, bottom_melt_simple);
   } else if (Na > 1 && phi[Na] < 0.00001 && phi[km1] <= psi_s_min / 2.0 && (thick[N_top + 1] / thick_0) < 1.01 && bf == 1) {
-    bottom_melt_simple(c);
+    regrid(c, bottom_melt_simple);
   } else if (phi[Na] > psi_s_min && Na < N && bf == 1) {
-    bottom_growth_simple(c);
+    regrid(c, bottom_growth_simple);
   } else if (phi[N] > psi_s_min && bf == 1) {
-    bottom_growth(c);
+    regrid(c, bottom_growth);
   } else if (thick[1] > 1.5 * thick_0) {
     c->melt_thick_output[2] = c->melt_thick_output[2] - thick[1];
-    top_grow(c);
+    regrid(c, top_grow);
     c->melt_thick_output[2] = c->melt_thick_output[2] + thick[1];
   } else if (thick[1] < 0.5 * thick_0) {
     c->melt_thick_output[2] = c->melt_thick_output[2] - thick[1];
-    top_melt(c);
+    regrid(c, top_melt);
     c->melt_thick_output[2] = c->melt_thick_output[2] + thick[1];
   }
 }
@@ -1324,7 +1400,10 @@ static void step_part_a(column *c) {
 
   /* brine flux due to expulsion :312-321 */
   expulsion_flux(c);
-  if (c->step + 1 != 1) mass_transfer(c, c->fl_m);
+  if (c->step + 1 != 1) {
+    mass_transfer(c, c->fl_m);
+    for (k = 1; k <= Na && c->n_bgc > 0; k++) FLB(k, k + 1) = -c->fl_m[k + 1];       /* :316-320 */
+  }
 
   for (k = Na; k >= 1; k--) c->S_bu[k] = S_abs[k] / m[k];                             /* :333-335 */
 }
@@ -1355,6 +1434,10 @@ static void take_snapshot(column *c) {
   s[SAMSIM_S_ENERGY_STORED] = c->energy_stored; s[SAMSIM_S_FRESHWATER] = c->freshwater; s[SAMSIM_S_TOTAL_RESIST] = c->total_resist;
   s[SAMSIM_S_THICKNESS] = c->thickness; s[SAMSIM_S_BULK_SALIN] = c->bulk_salin; s[SAMSIM_S_FL_REST] = c->fl_rest; s[SAMSIM_S_S_BU_BOTTOM] = c->S_bu_bottom;
   s[SAMSIM_S_DT2M] = c->dT2m; s[SAMSIM_S_PRECIP_SCALE] = c->precip_scale;
+  for (int t = 0; t < c->n_bgc && c->snap_bgc; t++) {
+    for (k = 1; k <= N; k++) c->snap_bgc[(size_t)t * N + (k - 1)] = c->bgc[t][k];
+    c->snap_bgc_bottom[t] = c->bgc_bottom[t];
+  }
   c->snap_valid = 1; c->snap_time = c->time; c->snap_step = c->step + 1; c->snap_N_active = c->N_active;
 }
 
@@ -1406,7 +1489,10 @@ static void step_part_b(column *c) {
   }
 
   /* bottom turbulence :450-457 */
-  if (g->turb_flag == 2) sub_turb_flux(g->T_bottom, c->S_bu_bottom, c->T[Na], &S_abs[Na], m[Na], g->dt);
+  if (g->turb_flag == 2) {
+    double turb = sub_turb_flux(g->T_bottom, c->S_bu_bottom, c->T[Na], &S_abs[Na], m[Na], g->dt);
+    for (int t = 0; t < c->n_bgc; t++) c->bgc[t][Na] = c->bgc[t][Na] - turb * (c->bgc[t][Na] / m[Na] - c->bgc_bottom[t]);
+  }
 
   /* gravity drainage :463-477 */
   if (g->grav_flag == 2 && Na > 1) { fl_grav_drain(c); CHECK(); }
@@ -1427,6 +1513,11 @@ static void step_part_b(column *c) {
     for (k = 1; k <= N; k++) sS += S_abs[k];
     for (k = 1; k <= N; k++) sm += m[k];
     c->S_bu_bottom = (g->S_total - sS) / (g->m_total - sm);
+    if (c->n_bgc > 0) {                                                                /* :575-577 (sic: tracer 1 sets them all) */
+      double sb = 0.0;
+      for (k = 1; k <= N; k++) sb += c->bgc[0][k];
+      for (int t = 0; t < c->n_bgc; t++) c->bgc_bottom[t] = (c->bgc_total[0] - sb) / (g->m_total - sm);
+    }
   }
 
   /* heat fluxes :584 */
@@ -1508,6 +1599,9 @@ static void step_part_b(column *c) {
     for (k = 1; k <= N; k++) { c->flush_v[k] = c->flush_v[k] + fv_old[k]; c->flush_h[k] = c->flush_h[k] + fh_old[k]; }
   }
 
+  /* tracer advection with this step's brine fluxes :742-747 */
+  if (c->n_bgc > 0) bgc_advection(c);
+
   /* layer dynamics :755-795 */
   if (Na > 1) {
     if (c->phi[Na] > psi_s_min || c->phi[Na - 1] <= psi_s_min / 2.0 || thick[1] / g->thick_0 > 1.5 || thick[1] / g->thick_0 < 0.5) {
@@ -1517,6 +1611,7 @@ static void step_part_b(column *c) {
     if (Na < N && thick[(Na + 1 < N) ? Na + 1 : N] == 0.0) {                          /* :772-783 scrub */
       c->T[Na + 1] = g->T_bottom; c->S_bu[Na + 1] = c->S_bu_bottom; c->H[Na + 1] = 0.0;
       c->psi_l[Na + 1] = 1.0; c->psi_s[Na + 1] = 0.0;
+      for (int t = 0; t < c->n_bgc; t++) c->bgc[t][Na + 1] = 0.0;
     }
   } else {
     if (c->phi[1] > psi_s_min) { layer_dynamics(c); CHECK(); }
@@ -1551,8 +1646,11 @@ struct oracle_handle {
   int flen;
   int64_t out_col0, out_ncols;
   int nthreads;
+  int n_bgc;
+  double *bgc_total;
 };
 
+static double *dupd(const double *p, int n);
 static double *lay_alloc(int N) { return (double *)calloc((size_t)N + 3, sizeof(double)); }
 
 int oracle_create(const samsim_config *cfg, int64_t ncol, oracle_handle **out) {
@@ -1588,9 +1686,67 @@ void oracle_destroy(oracle_handle *h) {
     free(c->H_abs); free(c->S_abs); free(c->m); free(c->thick); free(c->T); free(c->phi); free(c->psi_s); free(c->psi_l);
     free(c->psi_g); free(c->S_bu); free(c->S_br); free(c->H); free(c->V_ex); free(c->fl_Q); free(c->fl_m); free(c->fl_rad);
     free(c->ray); free(c->perm); free(c->flush_v); free(c->flush_h); free(c->snap_lay);
+    for (int t = 0; t < SAMSIM_MAX_NBGC; t++) free(c->bgc[t]);
+    free(c->flb); free(c->snap_bgc);
   }
+  free(h->bgc_total);
   free(h->cols); free(h->f_sw); free(h->f_lw); free(h->f_T2m); free(h->f_precip);
   free(h);
+}
+
+/* tracers: mirror of samsim_set_tracers / set_tracer_state / get_tracer_state / get_tracer_output (include/samsim.h) */
+int oracle_set_tracers(oracle_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total) {
+  if (!h || h->cfg.bgc_flag != 2 || n_bgc < 1 || n_bgc > SAMSIM_MAX_NBGC || !bgc_bottom) return SAMSIM_ERR_ARG;
+  if (h->cfg.tank_flag == 2 && !bgc_total) return SAMSIM_ERR_ARG;
+  int N = h->cfg.nlayer;
+  free(h->bgc_total);
+  h->bgc_total = bgc_total ? dupd(bgc_total, n_bgc) : NULL;
+  h->n_bgc = n_bgc;
+  for (int64_t i = 0; i < h->ncol; i++) {
+    column *c = &h->cols[i];
+    c->n_bgc = n_bgc; c->bgc_total = h->bgc_total;
+    for (int t = 0; t < n_bgc; t++) {
+      if (!c->bgc[t]) c->bgc[t] = lay_alloc(N);
+      c->bgc_bottom[t] = bgc_bottom[t];
+    }
+    if (!c->flb) c->flb = (double *)calloc((size_t)(N + 2) * (size_t)(N + 2), sizeof(double));
+    if (c->snap_lay && !c->snap_bgc) c->snap_bgc = (double *)calloc((size_t)SAMSIM_MAX_NBGC * N, sizeof(double));
+  }
+  return SAMSIM_OK;
+}
+
+int oracle_set_tracer_state(oracle_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols) {
+  if (!h || !bgc_abs || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  int N = h->cfg.nlayer;
+  for (int64_t i = 0; i < ncols; i++)
+    for (int t = 0; t < h->n_bgc; t++)
+      for (int k = 1; k <= N; k++) h->cols[col0 + i].bgc[t][k] = bgc_abs[((size_t)t * N + (k - 1)) * ncols + i];
+  return SAMSIM_OK;
+}
+
+int oracle_get_tracer_state(oracle_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols) {
+  if (!h || !bgc_abs || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  int N = h->cfg.nlayer;
+  for (int64_t i = 0; i < ncols; i++)
+    for (int t = 0; t < h->n_bgc; t++) {
+      for (int k = 1; k <= N; k++) bgc_abs[((size_t)t * N + (k - 1)) * ncols + i] = h->cols[col0 + i].bgc[t][k];
+      if (bgc_bottom) bgc_bottom[(size_t)t * ncols + i] = h->cols[col0 + i].bgc_bottom[t];
+    }
+  return SAMSIM_OK;
+}
+
+int oracle_get_tracer_output(oracle_handle *h, double *bgc_abs, double *bgc_bottom) {
+  if (!h || !bgc_abs || h->n_bgc < 1) return SAMSIM_ERR_ARG;
+  int N = h->cfg.nlayer; int64_t w = h->out_ncols;
+  for (int64_t i = 0; i < w; i++) {
+    column *c = &h->cols[h->out_col0 + i];
+    if (!c->snap_valid || !c->snap_bgc) return SAMSIM_ERR_NO_OUTPUT;
+    for (int t = 0; t < h->n_bgc; t++) {
+      for (int k = 0; k < N; k++) bgc_abs[((size_t)t * N + k) * w + i] = c->snap_bgc[(size_t)t * N + k];
+      if (bgc_bottom) bgc_bottom[(size_t)t * w + i] = c->snap_bgc_bottom[t];
+    }
+  }
+  return SAMSIM_OK;
 }
 
 void oracle_set_threads(oracle_handle *h, int n) { if (h && n > 0) h->nthreads = n; }
@@ -1770,6 +1926,7 @@ int oracle_set_output_window(oracle_handle *h, int64_t col0, int64_t ncols) {
     column *c = &h->cols[i];
     int in = (i >= col0 && i < col0 + ncols);
     if (in && !c->snap_lay) c->snap_lay = (double *)calloc((size_t)SAMSIM_NARR * N, sizeof(double));
+    if (in && h->n_bgc > 0 && !c->snap_bgc) c->snap_bgc = (double *)calloc((size_t)SAMSIM_MAX_NBGC * N, sizeof(double));
     if (!in && c->snap_lay) { free(c->snap_lay); c->snap_lay = NULL; c->snap_valid = 0; }
   }
   h->out_col0 = col0; h->out_ncols = ncols;

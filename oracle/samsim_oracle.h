@@ -41,6 +41,10 @@ int  oracle_set_output_window(oracle_handle *h, int64_t col0, int64_t ncols);
 int  oracle_get_output(oracle_handle *h, samsim_output_soa *o);
 int  oracle_get_status(oracle_handle *h, int32_t *status, int64_t *step, int32_t *layer);
 int  oracle_get_work(oracle_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
+int  oracle_set_tracers(oracle_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total);
+int  oracle_set_tracer_state(oracle_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols);
+int  oracle_get_tracer_state(oracle_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols);
+int  oracle_get_tracer_output(oracle_handle *h, double *bgc_abs, double *bgc_bottom);
 int  oracle_get_ensemble_stats(oracle_handle *h, int32_t nslots, const int32_t *slots, samsim_stat *out);
 void oracle_set_threads(oracle_handle *h, int nthreads);   /* columns over OpenMP threads (cpu_baseline) */
 void oracle_destroy(oracle_handle *h);

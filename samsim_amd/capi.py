@@ -191,6 +191,8 @@ class Solver:
             "get_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
             "get_work": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
             "get_ensemble_stats": [vp, i32, C.POINTER(C.c_int32), C.POINTER(Stat)],
+            "set_tracers": [vp, i32, dp, dp], "set_tracer_state": [vp, dp, i64, i64],
+            "get_tracer_state": [vp, dp, dp, i64, i64], "get_tracer_output": [vp, dp, dp],
         }
         for n, a in sig.items():
             f = self._f(n)
@@ -279,6 +281,33 @@ class Solver:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self._f("get_work")(self._h, C.byref(a), C.byref(b)), "get_work")
         return a.value, b.value
+
+    # -- passive tracers (bgc_flag 2)
+    def set_tracers(self, bgc_bottom, bgc_total=None):
+        """number of tracers = len(bgc_bottom); concentrations below the ice; tank totals for tank_flag 2"""
+        b = np.ascontiguousarray(bgc_bottom, dtype=np.float64)
+        t = None if bgc_total is None else np.ascontiguousarray(bgc_total, dtype=np.float64)
+        self.n_bgc = len(b)
+        self._chk(self._f("set_tracers")(self._h, self.n_bgc, _dp(b), _dp(t) if t is not None else None), "set_tracers")
+
+    def set_tracer_state(self, bgc_abs, col0: int = 0):
+        """bgc_abs[n_bgc][nlayer][ncols]"""
+        a = np.ascontiguousarray(bgc_abs, dtype=np.float64)
+        assert a.shape[:2] == (self.n_bgc, self.nlayer)
+        self._chk(self._f("set_tracer_state")(self._h, _dp(a), col0, a.shape[2]), "set_tracer_state")
+
+    def get_tracer_state(self, col0: int = 0, ncols: int | None = None):
+        n = self.ncol - col0 if ncols is None else ncols
+        a, b = np.zeros((self.n_bgc, self.nlayer, n)), np.zeros((self.n_bgc, n))
+        self._chk(self._f("get_tracer_state")(self._h, _dp(a), _dp(b), col0, n), "get_tracer_state")
+        return a, b
+
+    def get_tracer_output(self):
+        """tracer snapshot of the output window at the reference's output point: (bgc_abs, bgc_bottom)"""
+        w = self._out_window[1]
+        a, b = np.zeros((self.n_bgc, self.nlayer, w)), np.zeros((self.n_bgc, w))
+        self._chk(self._f("get_tracer_output")(self._h, _dp(a), _dp(b)), "get_tracer_output")
+        return a, b
 
     def ensemble_stats(self, names):
         """{name: Stat} over the columns without a STOP code; names from SCALARS or "N_active" (samsim_get_ensemble_stats)"""

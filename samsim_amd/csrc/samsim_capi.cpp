@@ -48,6 +48,10 @@ struct samsim_handle {
   double *spec = nullptr;      // hand-over block of the up sweep, [DEV_NSPEC][ncol]
   int32_t *flags = nullptr;    // COLF_* per column
   void *d_stat = nullptr;      // block partials of samsim_get_ensemble_stats
+  // passive tracers (bgc_flag 2)
+  double *bgc = nullptr, *bgc_bot = nullptr, *bfl = nullptr, *out_bgc = nullptr, *out_bgc_bot = nullptr;
+  int32_t n_bgc = 0;
+  double bgc_total0 = 0.0;
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
   int32_t flen = 0;
   double *out_lay = nullptr, *out_scal = nullptr;
@@ -83,7 +87,7 @@ int validate(const samsim_config &c) {
     return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || !in(c.tank_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
-  if (!in(c.albedo_flag, {1, 2}) || !in(c.freeboard_snow_flag, {0, 1}) || !in(c.snow_flush_flag, {0, 1}) || c.bgc_flag != 1)
+  if (!in(c.albedo_flag, {1, 2}) || !in(c.freeboard_snow_flag, {0, 1}) || !in(c.snow_flush_flag, {0, 1}) || !in(c.bgc_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
   return SAMSIM_OK;
 }
@@ -187,6 +191,7 @@ void advance_clock(samsim_handle *h, long long nsteps) {
 int launch(samsim_handle *h, long long nsteps) {
   if (nsteps <= 0) return SAMSIM_OK;
   if (h->cfg.atmoflux_flag == 2 && h->cfg.boundflux_flag == 2 && !h->f_sw) return SAMSIM_ERR_ARG;
+  if (h->cfg.bgc_flag == 2 && h->n_bgc < 1) return SAMSIM_ERR_ARG;   // samsim_set_tracers first
   const int s = h->slot;
   h->slot = (h->slot + 1) % kRing;
   HIPCHK(hipEventSynchronize(h->slot_done[s]));
@@ -202,6 +207,8 @@ int launch(samsim_handle *h, long long nsteps) {
   p.out_lay = h->out_lay; p.out_scal = h->out_scal; p.out_n_active = h->out_n_active;
   p.out_col0 = h->out_col0; p.out_ncols = h->out_ncols;
   p.p17 = h->p17; p.p14 = h->p14; p.tf_c3 = h->tf_c3;
+  p.bgc = h->bgc; p.bgc_bot = h->bgc_bot; p.bfl = h->bfl; p.out_bgc = h->out_bgc; p.out_bgc_bot = h->out_bgc_bot;
+  p.n_bgc = h->n_bgc; p.bgc_total0 = h->bgc_total0;
   HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
   HIPCHK(samsim_launch_step(&h->d_params[s], &p, h->stream));
   HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
@@ -305,6 +312,7 @@ void samsim_destroy(samsim_handle *h) {
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
   (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat);
+  (void)hipFree(h->bgc); (void)hipFree(h->bgc_bot); (void)hipFree(h->bfl); (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
   (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
   (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
   (void)hipFree(h->d_params);
@@ -458,6 +466,15 @@ int samsim_set_output_window(samsim_handle *h, int64_t col0, int64_t ncols) {
     HIPCHK(hipMemset(h->out_scal, 0, sizeof(double) * SAMSIM_NSCAL * w));
     HIPCHK(hipMemset(h->out_n_active, 0, sizeof(int32_t) * w));
   }
+  if (h->n_bgc > 0) {  // tracer snapshot follows the window
+    (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
+    h->out_bgc = h->out_bgc_bot = nullptr;
+    const size_t N = (size_t)h->cfg.nlayer, w = (size_t)(ncols > 0 ? ncols : 1);
+    HIPCHK(dalloc(&h->out_bgc, (size_t)h->n_bgc * N * w));
+    HIPCHK(dalloc(&h->out_bgc_bot, (size_t)h->n_bgc * w));
+    HIPCHK(hipMemset(h->out_bgc, 0, sizeof(double) * (size_t)h->n_bgc * N * w));
+    HIPCHK(hipMemset(h->out_bgc_bot, 0, sizeof(double) * (size_t)h->n_bgc * w));
+  }
   return SAMSIM_OK;
 }
 
@@ -498,6 +515,71 @@ int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *colu
   for (size_t i = 0; i < nc; ++i) tot += w[i];
   if (layer_cell_updates) *layer_cell_updates = tot;
   if (column_steps) *column_steps = (int64_t)h->clk.step * (int64_t)h->ncol;
+  return SAMSIM_OK;
+}
+
+// ---- passive tracers
+int samsim_set_tracers(samsim_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (h->cfg.bgc_flag != 2 || n_bgc < 1 || n_bgc > SAMSIM_MAX_NBGC || !bgc_bottom) return SAMSIM_ERR_ARG;
+  if (h->cfg.tank_flag == 2 && !bgc_total) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t N = (size_t)h->cfg.nlayer, nc = (size_t)h->ncol, w = (size_t)(h->out_ncols > 0 ? h->out_ncols : 1);
+  if (n_bgc != h->n_bgc) {
+    (void)hipFree(h->bgc); (void)hipFree(h->bgc_bot); (void)hipFree(h->bfl); (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
+    h->bgc = h->bgc_bot = h->bfl = h->out_bgc = h->out_bgc_bot = nullptr;
+    HIPCHK(dalloc(&h->bgc, (size_t)n_bgc * N * nc));
+    HIPCHK(dalloc(&h->bgc_bot, (size_t)n_bgc * nc));
+    HIPCHK(dalloc(&h->bfl, (size_t)BFL_NROW * N * nc));
+    HIPCHK(dalloc(&h->out_bgc, (size_t)n_bgc * N * w));
+    HIPCHK(dalloc(&h->out_bgc_bot, (size_t)n_bgc * w));
+    HIPCHK(hipMemsetAsync(h->bgc, 0, sizeof(double) * (size_t)n_bgc * N * nc, h->stream));
+    HIPCHK(hipMemsetAsync(h->out_bgc, 0, sizeof(double) * (size_t)n_bgc * N * w, h->stream));
+    HIPCHK(hipMemsetAsync(h->out_bgc_bot, 0, sizeof(double) * (size_t)n_bgc * w, h->stream));
+    h->n_bgc = n_bgc;
+  }
+  HIPCHK(hipMemsetAsync(h->bfl, 0, sizeof(double) * (size_t)BFL_NROW * N * nc, h->stream));
+  for (int t = 0; t < n_bgc; ++t) HIPCHK(fill(h->bgc_bot + (size_t)t * nc, nc, bgc_bottom[t], h->stream));
+  h->bgc_total0 = bgc_total ? bgc_total[0] : 0.0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return SAMSIM_OK;
+}
+
+int samsim_set_tracer_state(samsim_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!bgc_abs || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t N = (size_t)h->cfg.nlayer, nc = (size_t)h->ncol, w = (size_t)ncols;
+  HIPCHK(hipMemcpy2D(h->bgc + col0, nc * sizeof(double), bgc_abs, w * sizeof(double), w * sizeof(double), (size_t)h->n_bgc * N,
+                     hipMemcpyHostToDevice));
+  return SAMSIM_OK;
+}
+
+int samsim_get_tracer_state(samsim_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!bgc_abs || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t N = (size_t)h->cfg.nlayer, nc = (size_t)h->ncol, w = (size_t)ncols;
+  HIPCHK(hipMemcpy2D(bgc_abs, w * sizeof(double), h->bgc + col0, nc * sizeof(double), w * sizeof(double), (size_t)h->n_bgc * N,
+                     hipMemcpyDeviceToHost));
+  if (bgc_bottom)
+    HIPCHK(hipMemcpy2D(bgc_bottom, w * sizeof(double), h->bgc_bot + col0, nc * sizeof(double), w * sizeof(double), (size_t)h->n_bgc,
+                       hipMemcpyDeviceToHost));
+  return SAMSIM_OK;
+}
+
+int samsim_get_tracer_output(samsim_handle *h, double *bgc_abs, double *bgc_bottom) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!bgc_abs || h->n_bgc < 1) return SAMSIM_ERR_ARG;
+  if (!h->snap_valid) return SAMSIM_ERR_NO_OUTPUT;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t N = (size_t)h->cfg.nlayer, w = (size_t)h->out_ncols;
+  HIPCHK(hipMemcpy(bgc_abs, h->out_bgc, sizeof(double) * (size_t)h->n_bgc * N * w, hipMemcpyDeviceToHost));
+  if (bgc_bottom) HIPCHK(hipMemcpy(bgc_bottom, h->out_bgc_bot, sizeof(double) * (size_t)h->n_bgc * w, hipMemcpyDeviceToHost));
   return SAMSIM_OK;
 }
 

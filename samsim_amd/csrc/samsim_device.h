@@ -27,6 +27,16 @@ enum dev_spec {
   DEV_NSPEC
 };
 
+// rows of the tracer flux block: what the reference collects in fl_brine_bgc(N+1, N+1) (mo_data.f90:183)
+enum dev_bgc_flux {
+  BFL_E = 0,   // -fl_m(k+1) of expulsion_flux: layer k -> k+1                       (mo_grotz.f90:316-320)
+  BFL_D,       // fl_down(k) of fl_grav_drain: layer k -> ocean                      (mo_grav_drain.f90:179)
+  BFL_U,       // fl_up(k) of fl_grav_drain: layer k+1 -> k (k = N_active: ocean -> N_active)  (:181-183)
+  BFL_V,       // flush_v(k) of flush3: layer k -> k+1                                (mo_flush.f90:171-173)
+  BFL_H,       // flush_h(k) of flush3: layer k -> N_active                           (:169)
+  BFL_NROW
+};
+
 // per-column flag bits
 #define COLF_DIRTY 1    // prognostic layers changed since the last up sweep: the next step runs the full S1 sweep
 #define COLF_RESTART 2  // first step after samsim_set_state: RAY holds the previous Rayleigh numbers
@@ -56,6 +66,11 @@ struct DevParams {
   double *out_scal;      // [SAMSIM_NSCAL][out_ncols]
   int32_t *out_n_active; // [out_ncols]
   long long out_col0, out_ncols;
+  // passive tracers (bgc_flag 2): bgc [n_bgc][nlayer][ncol] amounts, bgc_bot [n_bgc][ncol] concentration of the water below,
+  // bfl [BFL_NROW][nlayer][ncol] this step's brine fluxes (the sparse rows of fl_brine_bgc), snapshot for the output window
+  double *bgc, *bgc_bot, *bfl, *out_bgc, *out_bgc_bot;
+  int32_t n_bgc;
+  double bgc_total0;     // bgc_total(1): the tank budget of mo_grotz.f90:576 reads tracer 1 only
   // host-evaluated constants: 10**(-17), 10**(-14) (mo_grav_drain.f90:105,112) and the float32 product
   // 5.33*10.0**(-7.0) of func_T_freeze (mo_functions.f90:246)
   double p17, p14, tf_c3;

@@ -138,6 +138,8 @@ struct Col {
   double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
   double psi_l_top;  // psi_l(1) of this step's Expulsion (the albedo reads it before the down sweep stores the psi arrays)
+  double bgc_flood;  // flood_brine of this step (fl_brine_bgc(N_active,1), mo_flood.f90:140-143)
+  bool bgc_grav;     // fl_grav_drain ran this step (its fl_brine_bgc assignment, mo_grav_drain.f90:179)
   bool psi_full;     // this step's down sweep stored psi_s / psi_l / psi_g for every layer (not only for layer 1)
 };
 
@@ -320,7 +322,17 @@ struct Ctx {
   double p17, p14, tf_c3;
   // salinity of the water below the ice: cfg.S_bu_bottom (uniform), or the column's tank budget with tank_flag 2 (mo_grotz.f90:573)
   double S_bu_bottom;
+  // passive tracers (bgc_flag 2, KGeneric only): amounts [n_bgc][N][ncol], concentration below the ice [n_bgc][ncol], this
+  // step's brine fluxes [BFL_NROW][N][ncol], snapshot of the output window
+  gdouble *bgc, *bgc_bot, *bfl, *out_bgc, *out_bgc_bot;
+  int n_bgc;
+  double bgc_total0;
 };
+#define BGC(t, k) (x.bgc + ((size_t)(t) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
+#define BGC_BOT(t) (x.bgc_bot + (size_t)(t) * c.ncol)[c.col]
+#define BFL(r, k) (x.bfl + ((size_t)(r) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
+// tracers exist only in the run-time-flag instantiation; in the fixed ones the test folds to false
+#define HAS_BGC (K::general && x.n_bgc > 0)
 
 
 // ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
@@ -706,6 +718,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     const double m_in = m;
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
+    if (HAS_BGC) BFL(BFL_E, k) = transfer ? -flm_next : 0.0;
     double S_abs = LAY(SAMSIM_A_S_ABS, k);
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
     // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
@@ -830,6 +843,7 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   LAY(SAMSIM_A_H_ABS, 1) = H1;
   LAY(SAMSIM_A_M, 1) = m1;
   LAY(SAMSIM_A_THICK, 1) = th1;
+  c.bgc_flood = flood_brine;
 }
 
 // ---------------------------------------------------------------- flood_simple, mo_flood.f90:167-210 (flood_flag 3)
@@ -895,7 +909,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
   int stop_layer = 0;
 
-  struct L { double T, S_bu, S_abs, H_abs, flup; bool ch; };
+  struct L { double T, S_bu, S_abs, H_abs, flup, fdown; bool ch; };
   double S_br_j = LAY(SAMSIM_A_S_BR, 1);  // S_br(j), prefetched one layer ahead
 
   // drain(j): gravity-drainage loss of layer j (mo_grav_drain.f90:144-170) and fl_up(j)
@@ -906,6 +920,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.H_abs = LAY(SAMSIM_A_H_ABS, j);
     r.ch = false;
+    r.fdown = 0.0;
     const double thick = LAY(SAMSIM_A_THICK, j);
     if (do_beer) {
       if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
@@ -931,6 +946,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
           heat_loss = heat_loss + flux * c_l * r.T;
           cum = cum + flux;
           r.flup = dmin(cum, psi_l * rho_l * thick);
+          r.fdown = flux;
           r.ch = true;
         }
       }
@@ -967,6 +983,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
       LAY(SAMSIM_A_S_ABS, k) = cur.S_abs;
       LAY(SAMSIM_A_H_ABS, k) = cur.H_abs;
     }
+    if (HAS_BGC) { BFL(BFL_D, k) = cur.fdown; BFL(BFL_U, k) = cur.flup; }
     minS = dmin(minS, cur.S_abs);
     flup_prev = cur.flup;
     cur = nxt;
@@ -1462,6 +1479,7 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     }
     LAY(SAMSIM_A_FLUSH_V, k) = LAY(SAMSIM_A_FLUSH_V, k) + fv;  // accumulated output, mo_grotz.f90:697-737
     LAY(SAMSIM_A_FLUSH_H, k) = LAY(SAMSIM_A_FLUSH_H, k) + fh;
+    if (HAS_BGC) { BFL(BFL_V, k) = fv; BFL(BFL_H, k) = fh; }
     sum_fh += fh;
     const double flm_next = -fv, flm_k = -fv_up;
     if (flm_next < 0.0) {
@@ -1510,66 +1528,145 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- layer_dynamics, mo_layer_dynamics.f90:64-716
+// ---------------------------------------------------------------- bgc_advection, mo_mass.f90:150-209
+// The reference collects the step's brine fluxes in the (N+1)^2 matrix fl_brine_bgc and loops over all of it; at most
+// four entries per row are ever set:   (i, i-1) fl_up(i-1)                    return flow of the gravity drainage
+//                                      (i, i+1) -fl_m(i+1) + flush_v(i)       expulsion, vertical flushing
+//                                      (i, N_active) flush_h(i)               horizontal flushing   [same entry for i = N_active-1]
+//                                      (i, N_active+1) fl_down(i) [+ the expulsion part of (N_active-1, N_active), sic]
+//                                      (N_active, 1) flood_brine,  (N_active+1, N_active) flood_brine + fl_up(N_active)
+// Every flux is upwind (brine concentration of the source layer), limited to a third of the source's content.  One pass
+// top -> bottom: what a layer gives to the layer above is added before that layer is stored (one layer of delay), what it
+// gives to the layer below / to the bottom layer is carried along.
+template <class K>
+__device__ RARE void bgc_advection(Col &c, const Ctx &x) {
+  const int Na = c.Na;
+  for (int t = 0; t < x.n_bgc; ++t) {
+    const double bottom = BGC_BOT(t);
+    double carry_dn = 0.0, to_bottom = 0.0, to_top = 0.0, pend = 0.0;
+    for (int i = 1; i <= Na; ++i) {
+      const double q = BGC(t, i);
+      const double br = q / dmax(LAY(SAMSIM_A_PSI_L, i) * LAY(SAMSIM_A_THICK, i) * rho_l, 0.000000000000001);
+      const double lim = q / 3.0;
+      const double E = BFL(BFL_E, i), V = BFL(BFL_V, i);
+      double F_up = (i >= 2) ? BFL(BFL_U, i - 1) : 0.0;
+      double F_dn = E + V, F_h = (i <= Na - 2) ? BFL(BFL_H, i) : 0.0, F_out = 0.0, F_top = 0.0;
+      if (i == Na - 1) F_dn = F_dn + BFL(BFL_H, i);                       // (N_active-1, N_active) holds both
+      if (i <= Na - 1) { if (c.bgc_grav) F_out = ((i == Na - 1) ? E : 0.0) + BFL(BFL_D, i); }
+      else {                                                               // i = N_active: (i, i+1) leaves the domain
+        double sh = 0.0;
+        for (int k = 1; k <= Na - 1; ++k) sh += BFL(BFL_H, k);
+        F_out = F_dn + sh; F_dn = 0.0;
+        if (Na == 2) F_up = F_up + c.bgc_flood; else F_top = c.bgc_flood;  // (N_active, 1)
+      }
+      const double f_up = dmin(F_up * br, lim), f_dn = dmin(F_dn * br, lim), f_h = dmin(F_h * br, lim);
+      const double f_out = dmin(F_out * br, lim), f_top = dmin(F_top * br, lim);
+      double temp = q;
+      if (i == Na && Na > 2) temp = temp - f_top;
+      if (i >= 2) temp = temp - f_up;
+      if (i < Na) temp = temp - f_dn;
+      if (i <= Na - 2) temp = temp - f_h;
+      temp = temp + carry_dn;                                              // from the layer above
+      if (i == Na) {
+        temp = temp + to_bottom;                                           // horizontal flushing of the layers above
+        temp = temp - f_out;
+        temp = temp + (c.bgc_flood + BFL(BFL_U, Na)) * bottom;            // (N_active+1, N_active): from the water below
+      } else {
+        temp = temp - f_out;
+      }
+      if (i >= 2) BGC(t, i - 1) = pend + f_up;                             // the layer above is complete now
+      pend = temp;
+      carry_dn = f_dn; to_bottom = to_bottom + f_h; to_top = f_top;
+    }
+    BGC(t, Na) = pend;
+    if (Na > 2 && to_top != 0.0) BGC(t, 1) = BGC(t, 1) + to_top;
+  }
+  for (int r = 0; r < BFL_NROW; ++r)                                       // fl_brine_bgc = 0, mo_grotz.f90:745
+    for (int k = 1; k <= Na; ++k) BFL(r, k) = 0.0;
+}
+
+// Regridding with tracers.  In the reference every statement of the regrid routines on S_abs / S_bu / S_bu_bottom has a twin
+// on bgc_temp / bgc_bulk / bgc_bottom (mo_layer_dynamics.f90:205-373).  Each routine below therefore takes `tr`: tr < 0 is
+// the routine proper; tr >= 0 replays it for tracer tr -- same control flow, the tracer standing in for S_abs, and nothing
+// else written (m, H_abs, thick, N_active stay as they are, so every replay and then the proper pass see the old profile).
+template <class K>
+__device__ __forceinline__ gdouble &salt_at(Col &c, const Ctx &x, int tr, int k) {
+  if (K::general && tr >= 0) return BGC(tr, k);
+  return LAY(SAMSIM_A_S_ABS, k);
+}
+template <class K>
+__device__ __forceinline__ double salt_below(Col &c, const Ctx &x, int tr) {
+  if (K::general && tr >= 0) return BGC_BOT(tr);
+  return x.S_bu_bottom;
+}
 struct LayerVals { double rho, S_bu, H; };
-__device__ __forceinline__ LayerVals layer_vals(Col &c, int k) {
+template <class K>
+__device__ __forceinline__ LayerVals layer_vals(Col &c, const Ctx &x, int tr, int k) {
   const double m = LAY(SAMSIM_A_M, k);
   LayerVals v;
   v.rho = m / LAY(SAMSIM_A_THICK, k);
-  v.S_bu = LAY(SAMSIM_A_S_ABS, k) / m;
+  v.S_bu = salt_at<K>(c, x, tr, k) / m;
   v.H = LAY(SAMSIM_A_H_ABS, k) / m;
   return v;
 }
 template <class K>
-__device__ __forceinline__ void set_layer(Col &c, int k, const LayerVals &v, double thick_0) {
-  LAY(SAMSIM_A_M, k) = v.rho * thick_0;
-  LAY(SAMSIM_A_S_ABS, k) = v.S_bu * v.rho * thick_0;
-  LAY(SAMSIM_A_H_ABS, k) = v.H * v.rho * thick_0;
+__device__ __forceinline__ void set_layer(Col &c, const Ctx &x, int tr, int k, const LayerVals &v, double thick_0) {
+  if (tr < 0) LAY(SAMSIM_A_M, k) = v.rho * thick_0;
+  salt_at<K>(c, x, tr, k) = v.S_bu * v.rho * thick_0;
+  if (tr < 0) LAY(SAMSIM_A_H_ABS, k) = v.H * v.rho * thick_0;
 }
 template <class K>
-__device__ __forceinline__ void zero_layer(Col &c, int k) {
-  LAY(SAMSIM_A_M, k) = 0.0; LAY(SAMSIM_A_S_ABS, k) = 0.0; LAY(SAMSIM_A_H_ABS, k) = 0.0; LAY(SAMSIM_A_THICK, k) = 0.0;
+__device__ __forceinline__ void zero_layer(Col &c, const Ctx &x, int tr, int k) {
+  salt_at<K>(c, x, tr, k) = 0.0;
+  if (tr < 0) { LAY(SAMSIM_A_M, k) = 0.0; LAY(SAMSIM_A_H_ABS, k) = 0.0; LAY(SAMSIM_A_THICK, k) = 0.0; }
 }
 
 // top_melt, mo_layer_dynamics.f90:191-327
 template <class K>
-__device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
+__device__ __forceinline__ void top_melt(Col &c, const Ctx &x, int tr) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thick_0 = g.thick_0;
   int Na = c.Na;
   // layer 1 absorbs layer 2
-  LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) + LAY(SAMSIM_A_M, 2);
-  LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) + LAY(SAMSIM_A_S_ABS, 2);
-  LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) + LAY(SAMSIM_A_H_ABS, 2);
-  LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + LAY(SAMSIM_A_THICK, 2);
+  salt_at<K>(c, x, tr, 1) = salt_at<K>(c, x, tr, 1) + salt_at<K>(c, x, tr, 2);
+  if (tr < 0) {
+    LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) + LAY(SAMSIM_A_M, 2);
+    LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) + LAY(SAMSIM_A_H_ABS, 2);
+    LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + LAY(SAMSIM_A_THICK, 2);
+  }
   // the layer values that later branches need from the OLD profile
   const bool have_mid = (Na == N);
   LayerVals old_top1 = {0, 0, 0};
-  if (have_mid) old_top1 = layer_vals(c, N_top + 1);
+  if (have_mid) old_top1 = layer_vals<K>(c, x, tr, N_top + 1);
   const int kend = (N_top - 1 < Na - 1) ? N_top - 1 : Na - 1;
-  for (int k = 2; k <= kend; ++k) set_layer<K>(c, k, layer_vals(c, k + 1), thick_0);  // reads old k+1 (not yet modified)
+  for (int k = 2; k <= kend; ++k) set_layer<K>(c, x, tr, k, layer_vals<K>(c, x, tr, k + 1), thick_0);  // reads old k+1 (not yet modified)
   if (Na <= N_top) {
-    zero_layer<K>(c, Na);
+    zero_layer<K>(c, x, tr, Na);
     Na = Na - 1;
   } else if (Na > N_top && Na <= N && LAY(SAMSIM_A_THICK, N_top + 1) / thick_0 < 1.00001) {
-    for (int k = N_top; k <= Na - 1; ++k) set_layer<K>(c, k, layer_vals(c, k + 1), thick_0);
-    zero_layer<K>(c, Na);
+    for (int k = N_top; k <= Na - 1; ++k) set_layer<K>(c, x, tr, k, layer_vals<K>(c, x, tr, k + 1), thick_0);
+    zero_layer<K>(c, x, tr, Na);
     Na = Na - 1;
   }
   if (Na == N && LAY(SAMSIM_A_THICK, N_top + 1) - thick_0 >= 0.000001) {
     double loss_m = thick_0 * old_top1.rho, loss_S = loss_m * old_top1.S_bu, loss_H = loss_m * old_top1.H;
-    LAY(SAMSIM_A_M, N_top) = loss_m; LAY(SAMSIM_A_S_ABS, N_top) = loss_S; LAY(SAMSIM_A_H_ABS, N_top) = loss_H;
+    salt_at<K>(c, x, tr, N_top) = loss_S;
+    if (tr < 0) { LAY(SAMSIM_A_M, N_top) = loss_m; LAY(SAMSIM_A_H_ABS, N_top) = loss_H; }
     for (int k = N_top + 1; k <= N_middle + N_top; ++k) {
-      const LayerVals below = layer_vals(c, k + 1);  // old values of k+1
-      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+      const LayerVals below = layer_vals<K>(c, x, tr, k + 1);  // old values of k+1
+      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = salt_at<K>(c, x, tr, k);
       m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
       const double shift = thick_0 * (double)(float)(N_middle - k + N_top) / (double)(float)(N_middle);
       loss_m = shift * below.rho; loss_S = loss_m * below.S_bu; loss_H = loss_m * below.H;
       m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
-      LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+      salt_at<K>(c, x, tr, k) = S_abs;
+      if (tr < 0) { LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; }
     }
-    for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thick_0 / (double)(float)(N_middle);
+    if (tr < 0)
+      for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thick_0 / (double)(float)(N_middle);
   }
+  if (tr >= 0) return;
   c.Na = Na;
   double sth = 0.0;
   for (int k = 1; k <= N; ++k) sth += LAY(SAMSIM_A_THICK, k);
@@ -1578,104 +1675,107 @@ __device__ __forceinline__ void top_melt(Col &c, const Ctx &x) {
 
 // top_grow, mo_layer_dynamics.f90:607-716
 template <class K>
-__device__ __forceinline__ void top_grow(Col &c, const Ctx &x) {
+__device__ __forceinline__ void top_grow(Col &c, const Ctx &x, int tr) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thick_0 = g.thick_0;
   int Na = c.Na;
-  LayerVals carry = layer_vals(c, 1);  // old values of layer k-1
+  LayerVals carry = layer_vals<K>(c, x, tr, 1);  // old values of layer k-1
   {
     const double loss_m = thick_0 * carry.rho, loss_S = loss_m * carry.S_bu, loss_H = loss_m * carry.H;
-    LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) - loss_m;
-    LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) - loss_S;
-    LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - loss_H;
-    LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - thick_0;
+    salt_at<K>(c, x, tr, 1) = salt_at<K>(c, x, tr, 1) - loss_S;
+    if (tr < 0) {
+      LAY(SAMSIM_A_M, 1) = LAY(SAMSIM_A_M, 1) - loss_m;
+      LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - loss_H;
+      LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - thick_0;
+    }
   }
   int kend = (N_top < Na) ? N_top : Na;
   if (Na > N_top && Na < N) kend = Na;  // second branch continues the same shift over N_top+1..Na
   for (int k = 2; k <= kend; ++k) {
-    const LayerVals old_k = layer_vals(c, k);
-    set_layer<K>(c, k, carry, thick_0);
+    const LayerVals old_k = layer_vals<K>(c, x, tr, k);
+    set_layer<K>(c, x, tr, k, carry, thick_0);
     carry = old_k;
   }
   if (Na <= N_top || (Na > N_top && Na < N)) {
     Na = Na + 1;
-    set_layer<K>(c, Na, carry, thick_0);  // S_bu*thick_0*rho and S_bu*rho*thick_0 differ in association:
-    LAY(SAMSIM_A_S_ABS, Na) = carry.S_bu * thick_0 * carry.rho;  // mo_layer_dynamics.f90:660-661,674-675
-    LAY(SAMSIM_A_H_ABS, Na) = carry.H * thick_0 * carry.rho;
-    LAY(SAMSIM_A_THICK, Na) = thick_0;
+    set_layer<K>(c, x, tr, Na, carry, thick_0);  // S_bu*thick_0*rho and S_bu*rho*thick_0 differ in association:
+    salt_at<K>(c, x, tr, Na) = carry.S_bu * thick_0 * carry.rho;  // mo_layer_dynamics.f90:660-661,674-675
+    if (tr < 0) { LAY(SAMSIM_A_H_ABS, Na) = carry.H * thick_0 * carry.rho; LAY(SAMSIM_A_THICK, Na) = thick_0; }
   } else if (Na == N) {
     // carry holds the old values of layer N_top
     double loss_m = thick_0 * carry.rho, loss_S = loss_m * carry.S_bu, loss_H = loss_m * carry.H;
     for (int k = N_top + 1; k <= N_middle + N_top; ++k) {
-      const LayerVals own = layer_vals(c, k);  // old values of k
-      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+      const LayerVals own = layer_vals<K>(c, x, tr, k);  // old values of k
+      double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = salt_at<K>(c, x, tr, k);
       m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
       const double shift = thick_0 * (double)(float)(N_middle - k + N_top) / (double)(float)(N_middle);
       loss_m = shift * own.rho; loss_S = loss_m * own.S_bu; loss_H = loss_m * own.H;
       m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
-      LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+      salt_at<K>(c, x, tr, k) = S_abs;
+      if (tr < 0) { LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; }
     }
-    for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thick_0 / (double)(float)(N_middle);
+    if (tr < 0)
+      for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thick_0 / (double)(float)(N_middle);
   }
-  c.Na = Na;
+  if (tr < 0) c.Na = Na;
 }
 
 // bottom_melt, mo_layer_dynamics.f90:341-427 (N_active == Nlayer)
 template <class K>
-__device__ __forceinline__ void bottom_melt(Col &c, const Ctx &x) {
+__device__ __forceinline__ void bottom_melt(Col &c, const Ctx &x, int tr) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle;
   const double thN = LAY(SAMSIM_A_THICK, N);
   double loss_m = 0.0, loss_S = 0.0, loss_H = 0.0;
   LayerVals carry = {0, 0, 0};
   for (int k = N_top + 1; k <= N_top + N_middle; ++k) {
-    const LayerVals own = layer_vals(c, k);
-    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const LayerVals own = layer_vals<K>(c, x, tr, k);
+    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = salt_at<K>(c, x, tr, k);
     m = m + loss_m; H_abs = H_abs + loss_H; S_abs = S_abs + loss_S;
     const double shift = thN * (k - N_top) / (double)(float)(N_middle);
     loss_m = shift * own.rho; loss_H = loss_m * own.H; loss_S = loss_m * own.S_bu;
     m = m - loss_m; H_abs = H_abs - loss_H; S_abs = S_abs - loss_S;
-    LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
-    LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thN / (double)(float)(N_middle);
+    salt_at<K>(c, x, tr, k) = S_abs;
+      if (tr < 0) { LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; }
+    if (tr < 0) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) - thN / (double)(float)(N_middle);
     carry = own;
   }
   for (int k = N_top + N_middle + 1; k <= N; ++k) {
-    const LayerVals own = layer_vals(c, k);
+    const LayerVals own = layer_vals<K>(c, x, tr, k);
     const double thick = LAY(SAMSIM_A_THICK, k);
-    LAY(SAMSIM_A_H_ABS, k) = carry.rho * thick * carry.H;
-    LAY(SAMSIM_A_S_ABS, k) = carry.rho * thick * carry.S_bu;
-    LAY(SAMSIM_A_M, k) = carry.rho * thick;
+    salt_at<K>(c, x, tr, k) = carry.rho * thick * carry.S_bu;
+    if (tr < 0) { LAY(SAMSIM_A_H_ABS, k) = carry.rho * thick * carry.H; LAY(SAMSIM_A_M, k) = carry.rho * thick; }
     carry = own;
   }
 }
 
 // bottom_growth, mo_layer_dynamics.f90:438-523 (N_active == Nlayer)
 template <class K>
-__device__ __forceinline__ void bottom_growth(Col &c, const Ctx &x) {
+__device__ __forceinline__ void bottom_growth(Col &c, const Ctx &x, int tr) {
   const samsim_config &g = x.p->cfg;
   const int N = c.N, N_top = g.n_top, N_middle = g.n_middle, N_bottom = g.n_bottom;
   const double thN = LAY(SAMSIM_A_THICK, N);
   double gain_m = 0.0, gain_S = 0.0, gain_H = 0.0;
   for (int k = N_top + 1; k <= N_top + N_middle; ++k) {
-    const LayerVals below = layer_vals(c, k + 1);
-    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const LayerVals below = layer_vals<K>(c, x, tr, k + 1);
+    double m = LAY(SAMSIM_A_M, k), H_abs = LAY(SAMSIM_A_H_ABS, k), S_abs = salt_at<K>(c, x, tr, k);
     m = m - gain_m; H_abs = H_abs - gain_H; S_abs = S_abs - gain_S;
     const double shift = thN * (k - N_top) / (double)(float)(N_middle);
     gain_m = shift * below.rho; gain_H = gain_m * below.H; gain_S = gain_m * below.S_bu;
     m = m + gain_m; H_abs = H_abs + gain_H; S_abs = S_abs + gain_S;
-    LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; LAY(SAMSIM_A_S_ABS, k) = S_abs;
+    salt_at<K>(c, x, tr, k) = S_abs;
+      if (tr < 0) { LAY(SAMSIM_A_M, k) = m; LAY(SAMSIM_A_H_ABS, k) = H_abs; }
   }
-  for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thN / (double)(float)(N_middle);
+  if (tr < 0)
+    for (int k = N_top + 1; k <= N_top + N_middle; ++k) LAY(SAMSIM_A_THICK, k) = LAY(SAMSIM_A_THICK, k) + thN / (double)(float)(N_middle);
   for (int k = N - N_bottom + 1; k <= N - 1; ++k) {
-    LAY(SAMSIM_A_H_ABS, k) = LAY(SAMSIM_A_H_ABS, k + 1);
-    LAY(SAMSIM_A_S_ABS, k) = LAY(SAMSIM_A_S_ABS, k + 1);
-    LAY(SAMSIM_A_M, k) = LAY(SAMSIM_A_M, k + 1);
+    salt_at<K>(c, x, tr, k) = salt_at<K>(c, x, tr, k + 1);
+    if (tr < 0) { LAY(SAMSIM_A_H_ABS, k) = LAY(SAMSIM_A_H_ABS, k + 1); LAY(SAMSIM_A_M, k) = LAY(SAMSIM_A_M, k + 1); }
   }
   const double mN = thN * rho_l;
-  LAY(SAMSIM_A_M, N) = mN;
-  LAY(SAMSIM_A_H_ABS, N) = mN * g.T_bottom * c_l;
-  LAY(SAMSIM_A_S_ABS, N) = mN * x.S_bu_bottom;
+  salt_at<K>(c, x, tr, N) = mN * salt_below<K>(c, x, tr);
+  if (tr < 0) { LAY(SAMSIM_A_M, N) = mN; LAY(SAMSIM_A_H_ABS, N) = mN * g.T_bottom * c_l; }
 }
 
 // layer_dynamics, mo_layer_dynamics.f90:64-175: exactly one branch per call, in priority order
@@ -1688,12 +1788,15 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   const double phi_Na = LAY(SAMSIM_A_PHI, Na), phi_km1 = LAY(SAMSIM_A_PHI, km1);
   const double phi_Nm1 = LAY(SAMSIM_A_PHI, N - 1), phi_N = LAY(SAMSIM_A_PHI, N);
   const double th_mid = LAY(SAMSIM_A_THICK, N_top + 1), th1 = LAY(SAMSIM_A_THICK, 1);
+  const int nt = HAS_BGC ? x.n_bgc : 0;   // tracer replays (tr = nt-1 .. 0) come first, the routine proper (tr = -1) last
   if (phi_Nm1 <= psi_s_min / 2.0 && phi_Na < 0.00001 && Na == N && th_mid / thick_0 > 1.000001 && bf == 1) {
-    bottom_melt<K>(c, x);
+    for (int tr = nt - 1; tr >= -1; --tr) bottom_melt<K>(c, x, tr);
   } else if (Na > 1 && Na < N && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && bf == 1) {
-    zero_layer<K>(c, Na); c.Na = Na - 1;  // bottom_melt_simple, :573-591
+    for (int tr = nt - 1; tr >= -1; --tr) zero_layer<K>(c, x, tr, Na);  // bottom_melt_simple, :573-591
+    c.Na = Na - 1;
   } else if (Na > 1 && phi_Na < 0.00001 && phi_km1 <= psi_s_min / 2.0 && (th_mid / thick_0) < 1.01 && bf == 1) {
-    zero_layer<K>(c, Na); c.Na = Na - 1;
+    for (int tr = nt - 1; tr >= -1; --tr) zero_layer<K>(c, x, tr, Na);
+    c.Na = Na - 1;
   } else if (phi_Na > psi_s_min && Na < N && bf == 1) {
     // bottom_growth_simple, :537-560
     const double mnew = thick_0 * rho_l;
@@ -1701,16 +1804,16 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_THICK, Na + 1) = thick_0;
     LAY(SAMSIM_A_M, Na + 1) = mnew;
     LAY(SAMSIM_A_H_ABS, Na + 1) = mnew * g.T_bottom * c_l;
-    LAY(SAMSIM_A_S_ABS, Na + 1) = mnew * x.S_bu_bottom;
+    for (int tr = nt - 1; tr >= -1; --tr) salt_at<K>(c, x, tr, Na + 1) = mnew * salt_below<K>(c, x, tr);
   } else if (phi_N > psi_s_min && bf == 1) {
-    bottom_growth<K>(c, x);
+    for (int tr = nt - 1; tr >= -1; --tr) bottom_growth<K>(c, x, tr);
   } else if (th1 > 1.5 * thick_0) {
     c.melt_out3 = c.melt_out3 - th1;
-    top_grow<K>(c, x);
+    for (int tr = nt - 1; tr >= -1; --tr) top_grow<K>(c, x, tr);
     c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
   } else if (th1 < 0.5 * thick_0) {
     c.melt_out3 = c.melt_out3 - th1;
-    top_melt<K>(c, x);
+    for (int tr = nt - 1; tr >= -1; --tr) top_melt<K>(c, x, tr);
     if (c.status) return;
     c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
   }
@@ -1757,6 +1860,12 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
 #undef OUT
     x.out_n_active[oc] = c.Na;
+    if (HAS_BGC) {
+      for (int t = 0; t < x.n_bgc; ++t) {
+        for (int k = 1; k <= c.N; ++k) x.out_bgc[((size_t)t * c.N + (k - 1)) * on + oc] = BGC(t, k);
+        x.out_bgc_bot[(size_t)t * on + oc] = BGC_BOT(t);
+      }
+    }
   }
   c.grav_drain = 0.0; c.grav_salt = 0.0; c.grav_temp = 0.0;
   c.melt_out1 = 0.0; c.melt_out2 = 0.0; c.melt_out3 = 0.0;
@@ -1840,6 +1949,9 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
       const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, x.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
       S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       LAY(SAMSIM_A_S_ABS, Na) = S_abs;
+      if (HAS_BGC) {  // the tracers of the bottom layer mix with the same coefficient, :358-360
+        for (int t = 0; t < x.n_bgc; ++t) { const double q = BGC(t, Na); BGC(t, Na) = q - turb * (q / m - BGC_BOT(t)); }
+      }
     }
 
     // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
@@ -1850,6 +1962,7 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     c.frad = 0.0;
     if (do_grav) {
       sweep_grav_drain<K>(c, x, do_beer, beer0);
+      c.bgc_grav = true;
       if (c.status) return;
     } else if (K::general && CFG(grav_flag) == 3 && Na > 1) {
       sweep_grav_drain_simple<K>(c, do_beer, beer0);
@@ -1892,6 +2005,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     c.liquid_precip = c.liquid_precip * c.precip_scale;
   }
 
+  c.bgc_flood = 0.0; c.bgc_grav = false;
   snow_fall<K>(c, x);                  // mo_grotz.f90:251-265
   snow_block<K>(c, x);                 // mo_grotz.f90:273-292
   if (c.status) return;
@@ -1912,7 +2026,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool flood_possible = (CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
-                     !(K::general && CFG(testcase) == 5 && c.step + 1 == 2);
+                     !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC;
 
   if (fused) {
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
@@ -1949,6 +2063,12 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     double sS = 0.0, sm = 0.0;
     for (int k = 1; k <= c.Na; ++k) { sS += LAY(SAMSIM_A_S_ABS, k); sm += LAY(SAMSIM_A_M, k); }
     x.S_bu_bottom = (g.S_total - sS) / (g.m_total - sm);
+    if (HAS_BGC) {  // :575-577 (sic: the budget of tracer 1 sets the concentration of every tracer)
+      double sb = 0.0;
+      for (int k = 1; k <= c.Na; ++k) sb += BGC(0, k);
+      const double v = (x.bgc_total0 - sb) / (g.m_total - sm);
+      for (int t = 0; t < x.n_bgc; ++t) BGC_BOT(t) = v;
+    }
   }
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
@@ -2046,6 +2166,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     }
   }
 
+  // tracer advection with this step's brine fluxes, mo_grotz.f90:742-747
+  if (HAS_BGC) bgc_advection<K>(c, x);
+
   // layer dynamics, mo_grotz.f90:755-795
   if (Na > 1) {
     const double th1 = LAY(SAMSIM_A_THICK, 1);
@@ -2062,6 +2185,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       LAY(SAMSIM_A_S_BU, Na + 1) = x.S_bu_bottom;
       LAY(SAMSIM_A_PSI_L, Na + 1) = 1.0;
       LAY(SAMSIM_A_PSI_S, Na + 1) = 0.0;
+      if (HAS_BGC) for (int t = 0; t < x.n_bgc; ++t) BGC(t, Na + 1) = 0.0;
     }
   } else {
     if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
@@ -2090,7 +2214,10 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
                                                                         int32_t *__restrict__ flags, const double *__restrict__ f_sw,
                                                                         const double *__restrict__ f_lw, const double *__restrict__ f_T2m,
                                                                         const double *__restrict__ f_precip, double *__restrict__ out_lay,
-                                                                        double *__restrict__ out_scal, int32_t *__restrict__ out_n_active) {
+                                                                        double *__restrict__ out_scal, int32_t *__restrict__ out_n_active,
+                                                                        double *__restrict__ bgc, double *__restrict__ bgc_bot,
+                                                                        double *__restrict__ bfl, double *__restrict__ out_bgc,
+                                                                        double *__restrict__ out_bgc_bot) {
   const DevParams &p = *pp;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.ncol) return;
@@ -2099,6 +2226,9 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.f_sw = (gcdouble *)f_sw; x.f_lw = (gcdouble *)f_lw; x.f_T2m = (gcdouble *)f_T2m; x.f_precip = (gcdouble *)f_precip;
   x.out_lay = (gdouble *)out_lay; x.out_scal = (gdouble *)out_scal; x.out_n_active = (gint32 *)out_n_active;
   x.scal = (gdouble *)scal;
+  x.bgc = (gdouble *)bgc; x.bgc_bot = (gdouble *)bgc_bot; x.bfl = (gdouble *)bfl;
+  x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
+  x.n_bgc = K::general ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   x.S_bu_bottom = (K::general && (K::fixed ? K::tank_flag : p.cfg.tank_flag) == 2) ? scal[(size_t)SAMSIM_S_S_BU_BOTTOM * (size_t)p.ncol + (size_t)col] : p.cfg.S_bu_bottom;
@@ -2189,10 +2319,12 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
-  auto kernel = flags_match<KSheba>(g) ? samsim_step_kernel<KSheba>
-                : flags_match<KPlate>(g) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
+  const bool tracers = g.bgc_flag == 2;   // tracer code exists in the run-time-flag instantiation only
+  auto kernel = (!tracers && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
+                : (!tracers && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
-                     hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active);
+                     hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active, hp->bgc, hp->bgc_bot, hp->bfl, hp->out_bgc,
+                     hp->out_bgc_bot);
   return hipGetLastError();
 }

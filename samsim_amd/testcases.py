@@ -95,6 +95,27 @@ def testcase4(ncol: int = 1, nlayer: int = 100, n_top: int = 20, n_bottom: int =
     return c, st
 
 
+def tracers(cfg: Config, st: State):
+    """the tracer set-up init(testcase) makes when it switches bgc on (testcase 1: mo_init.f90:921-942, 2: :1006-1020,
+    6: :1333-1345): sets cfg.bgc_flag = 2 and returns (bgc_bottom, bgc_total or None, bgc_abs[n_bgc][nlayer][ncol]);
+    the single initial water layer holds bgc_bottom * m(1)"""
+    tc = cfg.testcase
+    if tc == 1:
+        bottom, total = np.array([400.0, 500.0]), None
+    elif tc == 2:
+        bottom = np.array([385.0, 385.0])
+        total = bottom * RHO_L * 1.0              # bgc_bottom*rho_l*tank_depth, in this order
+    elif tc == 6:
+        bottom = np.array([385.0])
+        total = bottom * RHO_L * 0.159
+    else:
+        raise ValueError(f"init({tc}) of the reference runs without tracers")
+    cfg.bgc_flag = 2
+    q = np.zeros((len(bottom), cfg.nlayer, st.ncol))
+    q[:, 0, :] = bottom[:, None] * st.arr("m")[0][None, :]
+    return bottom, total, q
+
+
 def _tank(testcase, ncol, nlayer, n_top, n_bottom, tank_depth, alpha_stable, fl_q_bottom, T2m, T_top, T_bottom, S_bu_bottom,
           thick_0, dt, time_out, n_out):
     """the tank experiments (testcases 2, 6, 9): air temperature T2m over a tank of finite depth, boundflux_flag 3,

@@ -18,6 +18,9 @@ Fixtures are DATA only -- inputs and expected outputs:
   tc5_ref_fullprec.npz      testcase 5 (fixed fluxes, flushing of a 1 m slab), scalars at all 240 output points, layers at every 6th
   tc{2,6,9}_ref_fullprec.npz  the tank experiments (boundflux_flag 3, tank_flag 2; bgc off): scalars (incl. the evolving
                             S_bu_bottom) at all output points, layers at every 4th
+  tc{1,2,6}_bgc_ref.npz     the passive tracers of the testcases that ship with bgc_flag 2: bgc_abs and bgc_bottom at every
+                            output point (float64); the committed dat_bgc0{1,2}.{bu,br}.dat of testcase 1 are in
+                            tc1_reference_dat.npz
   tc7_ref_fullprec.npz      testcase 7 (SHEBA with the simple parametrisations): scalars of the first 131 output points (the
                             reference's fl_grav_drain_simple reads an uninitialised local, so its own trajectory depends on
                             stack history), layers at selected ones, and teacher-forcing pairs through the first
@@ -50,6 +53,20 @@ def run_ref(testcase, dump, env=None):
     return read_dump(os.path.join(RUN, dump))
 
 
+def read_bgc_dump(path):
+    """records of oracle/ref_hook/ref_output_hook.f90::output_bgc: (step, N_active, bgc_bottom[n_bgc], bgc_abs[n_bgc][Nlayer])"""
+    buf, pos, recs = np.fromfile(path, dtype=np.uint8), 0, []
+    while pos < len(buf):
+        step, na, nb, nl = (int(x) for x in buf[pos:pos + 16].view(np.int32))
+        pos += 16
+        bot = buf[pos:pos + 8 * nb].view(np.float64).copy()
+        pos += 8 * nb
+        a = buf[pos:pos + 8 * nb * nl].view(np.float64).reshape(nb, nl).copy()
+        pos += 8 * nb * nl
+        recs.append((step, na, bot, a))
+    return recs
+
+
 def pack(recs, with_layers=True):
     d = dict(step=np.array([r["step"] for r in recs]), N_active=np.array([r["N_active"] for r in recs]),
              time_counter=np.array([r["time_counter"] for r in recs]))
@@ -64,8 +81,9 @@ def pack(recs, with_layers=True):
 def reference_dat():
     d = {}
     base = os.path.join(REF, "reference_output", "Reference_testcase1_with_Version_2")
-    for n in ["T", "S_bu", "psi_s", "psi_l", "psi_g", "thick", "ray", "freeboard", "vital_signs", "grav_drain", "snow"]:
-        d[n] = np.loadtxt(os.path.join(base, f"dat_{n}.dat"))
+    for n in ["T", "S_bu", "psi_s", "psi_l", "psi_g", "thick", "ray", "freeboard", "vital_signs", "grav_drain", "snow",
+              "bgc01.bu", "bgc01.br", "bgc02.bu", "bgc02.br"]:
+        d[n.replace(".", "_")] = np.loadtxt(os.path.join(base, f"dat_{n}.dat"))
     with open(os.path.join(base, "dat_settings.dat")) as f:
         d["settings_text"] = np.array(f.read())
     np.savez_compressed(os.path.join(OUT, "tc1_reference_dat.npz"), **d)
@@ -146,6 +164,13 @@ def main():
         for k, v in pack(recs, with_layers=False).items():
             d["all_" + k] = v
         np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
+    # --- tracers (bgc on, as init(1), init(2), init(6) ship): bgc_abs and bgc_bottom at every output point
+    for tc in (1, 2, 6):
+        cached(tc, f"tc{tc}_bgc.bin")
+        r = read_bgc_dump(os.path.join(RUN, f"tc{tc}_bgc.bin.bgc"))
+        np.savez_compressed(os.path.join(OUT, f"tc{tc}_bgc_ref.npz"), step=np.array([x[0] for x in r]),
+                            N_active=np.array([x[1] for x in r]), bgc_bottom=np.stack([x[2] for x in r]),
+                            bgc_abs=np.stack([x[3] for x in r]))
     recs = cached(7, "tc7_dump.bin", {"SAMSIM_REF_MAXSTEPS": "6000000"})
     sel = [0, 1, 2, 10, 40, 80, 120, 130]
     d = pack([recs[i] for i in sel])

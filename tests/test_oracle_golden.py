@@ -218,6 +218,53 @@ def test_tank_experiments_bitwise(tc, nout):
     assert ref["all_s_S_bu_bottom"].max() > cfg.S_bu_bottom + 0.2 and not o.get_status()[0].any()
 
 
+def bgc_bu_br(bgc_abs, bgc_bottom, m, psi_l, thick, na):
+    """output_bgc, mo_output.f90:156-188: the bulk and brine concentrations the reference prints per tracer"""
+    nb, nl = bgc_abs.shape
+    bu, br = np.zeros((nb, nl)), np.zeros((nb, nl))
+    for t in range(nb):
+        for k in range(nl):
+            if k < na:
+                if m[k] != 0.0:
+                    bu[t, k] = bgc_abs[t, k] / m[k]
+                    br[t, k] = bgc_abs[t, k] / psi_l[k] / thick[k] / 1028.0 if (psi_l[k] != 0.0 and thick[k] != 0.0) else 0.0
+            else:
+                bu[t, k] = br[t, k] = bgc_bottom[t]
+    return bu, br
+
+
+@pytest.mark.parametrize("tc,nout", [(1, 72), (2, 120), (6, 156)])
+def test_passive_tracers_bitwise(tc, nout):
+    """bgc_flag 2 as init(1), init(2), init(6) ship it: expulsion / gravity-drainage / flushing brine
+    fluxes collected in fl_brine_bgc, bgc_advection, bottom mixing, regridding of the tracers, the tank's bgc_bottom budget.
+    bgc_abs and bgc_bottom at every output point against the flang-built reference, bit for bit; for testcase 1 also the
+    reference's committed dat_bgc0{1,2}.{bu,br}.dat (F16.8)"""
+    cfg, st = getattr(tcs, f"testcase{tc}")(1)
+    bottom, total, q = tcs.tracers(cfg, st)
+    o = oracle_solver(cfg, 1)
+    o.set_tracers(bottom, total)
+    o.set_state(st)
+    o.set_tracer_state(q)
+    o.set_clock()
+    ref = golden(f"tc{tc}_bgc_ref.npz")
+    dat = golden("tc1_reference_dat.npz") if tc == 1 else None
+    assert len(ref["step"]) == nout
+    for i in range(nout):
+        out = o.run_to_output()
+        a, b = o.get_tracer_output()
+        assert out.step == ref["step"][i] and out.n_active[0] == ref["N_active"][i]
+        assert np.array_equal(a[:, :, 0], ref["bgc_abs"][i]), f"tc{tc} output {i}: bgc_abs"
+        assert np.array_equal(b[:, 0], ref["bgc_bottom"][i]), f"tc{tc} output {i}: bgc_bottom"
+        if dat is not None:
+            bu, br = bgc_bu_br(a[:, :, 0], b[:, 0], out.arr("m")[:, 0], out.arr("psi_l")[:, 0], out.arr("thick")[:, 0],
+                               int(out.n_active[0]))
+            for t in range(2):
+                for name, v in ((f"bgc0{t + 1}_bu", bu[t]), (f"bgc0{t + 1}_br", br[t])):
+                    assert np.abs(np.round(v, 8) - dat[name][i]).max() <= 1.1e-8 * max(1.0, np.abs(dat[name][i]).max()), (i, name)
+    if total is not None:
+        assert ref["bgc_bottom"].max() > bottom.max() + 1.0        # the tank's water gets richer as the ice rejects tracer
+
+
 def test_tc7_simple_parametrisations():
     """testcase 7 (albedo 1, grav_flag 3, flush_flag 4, flood_flag 3 on SHEBA forcing).  The reference's
     fl_grav_drain_simple accumulates into a local it never initialises (mo_grav_drain.f90:226,246-248), so the reference's
