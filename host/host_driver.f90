@@ -29,6 +29,9 @@ MODULE mo_data
   INTEGER             :: i_time, i_time_out
   REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp, T2m = 0._wp, tank_depth = 0._wp
   INTEGER             :: N_bgc = 1
+  REAL(c_double), TARGET :: bgc_bottom(8) = 0._wp, bgc_total(8) = 0._wp   !< tracers, mo_data.f90:187,193
+  REAL(c_double), ALLOCATABLE, TARGET :: bgc_abs(:, :, :)                  !< (ncol, Nlayer, N_bgc)
+  CHARACTER*12000     :: format_bgc
   ! host copies: SoA blocks, column fastest (= C layout [array][layer][column])
   REAL(c_double), ALLOCATABLE, TARGET    :: lay(:, :, :), scal(:, :)
   INTEGER(c_int32_t), ALLOCATABLE, TARGET :: n_active(:)
@@ -59,14 +62,14 @@ CONTAINS
   !! 5 (:1210-1273) and 7 (:1360-1395); common tail mo_init.f90:1981-2031.  Namelist group &samsim_flags (unit nml_unit, if > 0) overrides the settings.
   SUBROUTINE init(testcase, nml_unit)
     INTEGER, INTENT(in) :: testcase, nml_unit
-    INTEGER :: Nlayer, N_top, N_bottom, ios
+    INTEGER :: Nlayer, N_top, N_bottom, ios, k_bgc
     INTEGER :: boundflux_flag, atmoflux_flag, albedo_flag, grav_flag, flush_flag, flood_flag, grav_heat_flag, &
                flush_heat_flag, harmonic_flag, salt_flag, turb_flag, bottom_flag, precip_flag, freeboard_snow_flag, &
-               snow_flush_flag
+               snow_flush_flag, bgc_flag
     REAL(wp) :: dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush
     NAMELIST /samsim_flags/ Nlayer, N_top, N_bottom, boundflux_flag, atmoflux_flag, albedo_flag, grav_flag, flush_flag, &
          flood_flag, grav_heat_flag, flush_heat_flag, harmonic_flag, salt_flag, turb_flag, bottom_flag, precip_flag, &
-         freeboard_snow_flag, snow_flush_flag, dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush, &
+         freeboard_snow_flag, snow_flush_flag, bgc_flag, dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush, &
          fl_q_bottom, T_top, T2m, tank_depth
 
     CALL default_flags()
@@ -129,13 +132,22 @@ CONTAINS
        STOP 4321
     END IF
 
+    ! tracers as init(testcase) switches them on (mo_init.f90:921-942, 1006-1020, 1333-1345); &samsim_flags bgc_flag = 1 turns them off
+    IF (testcase == 1) THEN
+       cfg%bgc_flag = 2; N_bgc = 2; bgc_bottom(1) = 400._wp; bgc_bottom(2) = 500._wp
+    ELSE IF (testcase == 2) THEN
+       cfg%bgc_flag = 2; N_bgc = 2; bgc_bottom(1:2) = 385._wp
+    ELSE IF (testcase == 6) THEN
+       cfg%bgc_flag = 2; N_bgc = 1; bgc_bottom(1) = 385._wp
+    END IF
+
     IF (nml_unit > 0) THEN
        Nlayer = cfg%nlayer; N_top = cfg%n_top; N_bottom = cfg%n_bottom
        boundflux_flag = cfg%boundflux_flag; atmoflux_flag = cfg%atmoflux_flag; albedo_flag = cfg%albedo_flag
        grav_flag = cfg%grav_flag; flush_flag = cfg%flush_flag; flood_flag = cfg%flood_flag
        grav_heat_flag = cfg%grav_heat_flag; flush_heat_flag = cfg%flush_heat_flag; harmonic_flag = cfg%harmonic_flag
        salt_flag = cfg%salt_flag; turb_flag = cfg%turb_flag; bottom_flag = cfg%bottom_flag; precip_flag = cfg%precip_flag
-       freeboard_snow_flag = cfg%freeboard_snow_flag; snow_flush_flag = cfg%snow_flush_flag
+       freeboard_snow_flag = cfg%freeboard_snow_flag; snow_flush_flag = cfg%snow_flush_flag; bgc_flag = cfg%bgc_flag
        dt = cfg%dt; thick_0 = cfg%thick_0; time_out = cfg%time_out; time_total = cfg%time_total
        T_bottom = cfg%T_bottom; S_bu_bottom = cfg%S_bu_bottom; k_snow_flush = cfg%k_snow_flush
        REWIND(nml_unit)
@@ -149,7 +161,7 @@ CONTAINS
        cfg%grav_flag = grav_flag; cfg%flush_flag = flush_flag; cfg%flood_flag = flood_flag
        cfg%grav_heat_flag = grav_heat_flag; cfg%flush_heat_flag = flush_heat_flag; cfg%harmonic_flag = harmonic_flag
        cfg%salt_flag = salt_flag; cfg%turb_flag = turb_flag; cfg%bottom_flag = bottom_flag; cfg%precip_flag = precip_flag
-       cfg%freeboard_snow_flag = freeboard_snow_flag; cfg%snow_flush_flag = snow_flush_flag
+       cfg%freeboard_snow_flag = freeboard_snow_flag; cfg%snow_flush_flag = snow_flush_flag; cfg%bgc_flag = bgc_flag
        cfg%dt = dt; cfg%thick_0 = thick_0; cfg%time_out = time_out; cfg%time_total = time_total
        cfg%T_bottom = T_bottom; cfg%S_bu_bottom = S_bu_bottom; cfg%k_snow_flush = k_snow_flush
     END IF
@@ -200,6 +212,16 @@ CONTAINS
        ELSE
           lay(:, 1, A_H_ABS) = 0._wp
        END IF
+    END IF
+    IF (cfg%bgc_flag == 2) THEN
+       IF (cfg%tank_flag == 2) bgc_total(1:N_bgc) = bgc_bottom(1:N_bgc)*rho_l*tank_depth
+       ALLOCATE(bgc_abs(ncol, cfg%nlayer, N_bgc))
+       bgc_abs = 0._wp
+       DO k_bgc = 1, N_bgc
+          bgc_abs(:, 1, k_bgc) = bgc_bottom(k_bgc)*lay(:, 1, A_M)        ! bgc_abs(1,:) = bgc_bottom(:)*m(1)
+       END DO
+    ELSE
+       N_bgc = 1
     END IF
     PRINT *, 'Initialization of testcase complete, testcase:', testcase
   END SUBROUTINE init
@@ -358,6 +380,52 @@ CONTAINS
     WRITE(50, format_melt)  oscal(S_MELT_OUT1), oscal(S_MELT_OUT2), oscal(S_MELT_OUT3)
   END SUBROUTINE output
 
+  !> output_begin_bgc, mo_output.f90:354-384: two files per tracer, F16.8
+  SUBROUTINE output_begin_bgc(Nlayer)
+    INTEGER(c_int32_t), INTENT(in) :: Nlayer
+    CHARACTER(len=16)  :: n
+    CHARACTER(len=64)  :: name
+    INTEGER :: k
+    WRITE(n, '(I0)') Nlayer + 1
+    format_bgc = '('//TRIM(n)//'(F16.8,2x))'
+    DO k = 1, N_bgc
+       WRITE(name, '(A,I2.2,A)') './output/dat_bgc', k, '.bu.dat'
+       OPEN(2*k + 400, file=TRIM(name), STATUS='replace', Recl=12288)
+       WRITE(name, '(A,I2.2,A)') './output/dat_bgc', k, '.br.dat'
+       OPEN(2*k + 401, file=TRIM(name), STATUS='replace', Recl=12288)
+    END DO
+  END SUBROUTINE output_begin_bgc
+
+  !> output_bgc, mo_output.f90:156-188: bulk and brine concentration per layer, the water's below N_active
+  SUBROUTINE output_bgc(Nlayer, N_active, obgc, obot, olay)
+    INTEGER(c_int32_t), INTENT(in) :: Nlayer, N_active
+    REAL(c_double),     INTENT(in) :: obgc(Nlayer, N_bgc), obot(N_bgc), olay(:, :)
+    REAL(wp) :: bgc_bu(Nlayer), bgc_br(Nlayer)
+    INTEGER :: k, kk
+    DO k = 1, N_bgc
+       DO kk = 1, Nlayer
+          IF (kk <= N_active) THEN
+             IF (olay(kk, A_M) .NE. 0._wp) THEN
+                bgc_bu(kk) = obgc(kk, k)/olay(kk, A_M)
+                IF (olay(kk, A_PSI_L) .NE. 0._wp .AND. olay(kk, A_THICK) .NE. 0) THEN
+                   bgc_br(kk) = obgc(kk, k)/olay(kk, A_PSI_L)/olay(kk, A_THICK)/rho_l
+                ELSE
+                   bgc_br(kk) = 0._wp
+                END IF
+             ELSE
+                bgc_bu(kk) = 0._wp
+                bgc_br(kk) = 0._wp
+             END IF
+          ELSE
+             bgc_bu(kk) = obot(k)
+             bgc_br(kk) = obot(k)
+          END IF
+       END DO
+       WRITE(2*k + 400, format_bgc) bgc_bu
+       WRITE(2*k + 401, format_bgc) bgc_br
+    END DO
+  END SUBROUTINE output_bgc
+
   !> One row per output point with the ensemble statistics (count, then mean / min / max / std of thickness, snow thickness,
   !! bulk salinity, freeboard, surface temperature and N_active): what stands in for "one .dat row per column" when the
   !! run holds 10^5..10^6 columns (SURVEY.md section 8 f.1).  Column out_col keeps its own dat_*.dat files.
@@ -380,6 +448,11 @@ CONTAINS
     DO u = 40, 51
        IF (u /= 44) CLOSE(u)
     END DO
+    IF (cfg%bgc_flag == 2) THEN
+       DO u = 1, N_bgc
+          CLOSE(2*u + 400); CLOSE(2*u + 401)
+       END DO
+    END IF
   END SUBROUTINE output_end
 END MODULE mo_output
 
@@ -468,7 +541,7 @@ CONTAINS
     TYPE(samsim_state_soa)  :: st
     TYPE(samsim_output_soa) :: o
     TYPE(samsim_clock)      :: clk
-    REAL(c_double), ALLOCATABLE, TARGET :: olay(:, :, :), oscal(:, :)
+    REAL(c_double), ALLOCATABLE, TARGET :: olay(:, :, :), oscal(:, :), obgc(:, :, :), obot(:, :)
     INTEGER(c_int32_t), ALLOCATABLE, TARGET :: ona(:), status(:), err_layer(:)
     INTEGER(c_int64_t), ALLOCATABLE :: err_step(:)
     INTEGER(c_int64_t) :: n, done, total, cells, colsteps
@@ -477,6 +550,7 @@ CONTAINS
 
     CALL init(testcase, nml_unit)
     CALL output_begin(cfg%nlayer)
+    IF (cfg%bgc_flag == 2) CALL output_begin_bgc(cfg%nlayer)
     CALL output_settings(description, testcase)
 
     CALL samsim_check(samsim_create(cfg, ncol, INT(device, c_int32_t), h), 'samsim_create')
@@ -493,7 +567,20 @@ CONTAINS
     END IF
     st%ncol = ncol; st%nlayer = cfg%nlayer; st%narr = SAMSIM_NARR
     st%lay = c_loc(lay); st%scal = c_loc(scal); st%n_active = c_loc(n_active)
+    IF (cfg%bgc_flag == 2) THEN
+       IF (cfg%tank_flag == 2) THEN
+          CALL samsim_check(samsim_set_tracers(h, INT(N_bgc, c_int32_t), bgc_bottom, c_loc(bgc_total)), 'samsim_set_tracers')
+       ELSE
+          CALL samsim_check(samsim_set_tracers(h, INT(N_bgc, c_int32_t), bgc_bottom, c_null_ptr), 'samsim_set_tracers')
+       END IF
+       CALL samsim_check(samsim_set_tracer_state(h, bgc_abs, 0_c_int64_t, ncol), 'samsim_set_tracer_state')
+       ALLOCATE(obgc(1, cfg%nlayer, N_bgc), obot(1, N_bgc))
+    END IF
     CALL samsim_check(samsim_set_state(h, st, 0_c_int64_t), 'samsim_set_state')
+    IF (cfg%bgc_flag == 2 .AND. (LEN_TRIM(restart_in) > 0 .OR. LEN_TRIM(restart_out) > 0)) THEN
+       PRINT *, 'restart files do not hold the tracers: run with &samsim_flags bgc_flag = 1 or without restart_in/restart_out'
+       STOP 6
+    END IF
     IF (LEN_TRIM(restart_in) > 0) CALL read_restart(h, restart_in)
     CALL samsim_check(samsim_set_output_window(h, INT(out_col - 1, c_int64_t), 1_c_int64_t), 'samsim_set_output_window')
     ALLOCATE(olay(1, cfg%nlayer, SAMSIM_NARR), oscal(1, SAMSIM_NSCAL), ona(1))
@@ -512,6 +599,10 @@ CONTAINS
        IF (samsim_steps_to_output(h) == cfg%i_time_out + 1 .OR. done == 1) THEN   ! an output point was just passed
           CALL samsim_check(samsim_get_output(h, o), 'samsim_get_output')
           CALL output(cfg%nlayer, olay(1, :, :), oscal(1, :))
+          IF (cfg%bgc_flag == 2) THEN
+             CALL samsim_check(samsim_get_tracer_output(h, obgc, obot), 'samsim_get_tracer_output')
+             CALL output_bgc(cfg%nlayer, ona(1), obgc(1, :, :), obot(1, :), olay(1, :, :))
+          END IF
           CALL output_ensemble(h, o%time)
           time = o%time
           thick1 = olay(1, 1, A_THICK)

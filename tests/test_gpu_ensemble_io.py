@@ -113,9 +113,9 @@ def test_fortran_host_restart_and_ensemble_file(tmp_path):
         r = subprocess.run([HOST], cwd=d, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return r.stdout
-    run(tmp_path / "full", "&samsim_run testcase=1, ncol=96, max_steps=12000 /\n")
-    run(tmp_path / "part1", "&samsim_run testcase=1, ncol=96, max_steps=7300, restart_out='../tc1.chk' /\n")
-    out = run(tmp_path / "part2", "&samsim_run testcase=1, ncol=96, max_steps=12000, restart_in='../tc1.chk' /\n")
+    run(tmp_path / "full", "&samsim_run testcase=1, ncol=96, max_steps=12000 /\n&samsim_flags bgc_flag=1 /\n")
+    run(tmp_path / "part1", "&samsim_run testcase=1, ncol=96, max_steps=7300, restart_out='../tc1.chk' /\n&samsim_flags bgc_flag=1 /\n")
+    out = run(tmp_path / "part2", "&samsim_run testcase=1, ncol=96, max_steps=12000, restart_in='../tc1.chk' /\n&samsim_flags bgc_flag=1 /\n")
     assert "restarted from" in out
     hdr = checkpoint.read_header(str(tmp_path / "tc1.chk"))
     assert (hdr["ncol"], hdr["nlayer"], hdr["step"], hdr["narr"], hdr["testcase"]) == (96, 90, 7300, 15, 1)

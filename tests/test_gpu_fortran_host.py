@@ -46,6 +46,13 @@ def test_fortran_host_testcase1_reproduces_reference_dat(tmp_path):
     settings = (tmp_path / "output" / "dat_settings.dat").read_text()
     # (A16 truncates the 17-character key strings, exactly as in the reference's dat_settings.dat)
     assert "boundflux_flag          1" in settings and "ncol                      64" in settings
+    # init(1) ships with two passive tracers: dat_bgc0{1,2}.{bu,br}.dat against the committed files (F16.8)
+    assert "bgc_flag                2" in settings
+    for t in (1, 2):
+        for kind in ("bu", "br"):
+            got, want = np.loadtxt(tmp_path / "output" / f"dat_bgc0{t}.{kind}.dat"), ref[f"bgc0{t}_{kind}"]
+            assert got.shape == want.shape == (72, 90)
+            assert np.abs(got - want).max() <= 2e-8 * max(1.0, np.abs(want).max()), f"dat_bgc0{t}.{kind}"
 
 
 @pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")
