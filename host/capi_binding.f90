@@ -73,6 +73,15 @@ MODULE mo_samsim_capi
        REAL(c_double), INTENT(in) :: fl_sw(*), fl_lw(*), T2m(*), precip(*)
        TYPE(c_ptr), VALUE :: dT2m_col, precip_scale_col
      END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_forcing_sites(h, nsites, len, fl_sw, fl_lw, T2m, precip, site_of_column, dT2m_col, &
+          precip_scale_col) BIND(C, name='samsim_set_forcing_sites')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       INTEGER(c_int32_t), VALUE :: nsites, len
+       REAL(c_double), INTENT(in) :: fl_sw(*), fl_lw(*), T2m(*), precip(*)      ! (len, nsites)
+       INTEGER(c_int32_t), INTENT(in) :: site_of_column(*)                      ! 0-based
+       TYPE(c_ptr), VALUE :: dT2m_col, precip_scale_col
+     END FUNCTION
      INTEGER(c_int) FUNCTION samsim_set_state(h, s, col0) BIND(C, name='samsim_set_state')
        IMPORT
        TYPE(c_ptr), VALUE :: h

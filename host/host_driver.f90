@@ -4,7 +4,7 @@
 !! runs on the GPU behind the C-ABI of include/samsim.h for `ncol` columns at once.
 !!
 !! New surface the reference does not have (SURVEY.md, introduction): a namelist file `samsim.nml`
-!!   &samsim_run   testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out /
+!!   &samsim_run   testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out, sites /
 !!   &samsim_flags <any flag of mo_data.f90:136-155 or scalar set by mo_init> /       (overrides init(testcase))
 !! `dat_settings.dat` stays the echo of what was actually used.
 !!
@@ -25,6 +25,7 @@ MODULE mo_data
   INTEGER             :: device = 0, out_col = 1
   LOGICAL             :: perturb = .FALSE.   !< per-column T2m / precipitation perturbation (SURVEY.md 8d cfg3)
   INTEGER(c_int64_t)  :: max_steps = -1
+  CHARACTER(len=256)  :: sites(16) = ' '      !< directories with flux_sw/flux_lw/T2m/precip.txt.input; column c reads sites(MOD(c-1,n)+1)
   CHARACTER(len=1024) :: restart_in = ' ', restart_out = ' '   !< binary checkpoint files (samsim_amd/checkpoint.py format)
   INTEGER             :: i_time, i_time_out
   REAL(wp)            :: fl_q_bottom = 0._wp, T_top = 0._wp, fl_sw = 0._wp, fl_rest = 0._wp, T2m = 0._wp, tank_depth = 0._wp
@@ -36,7 +37,7 @@ MODULE mo_data
   REAL(c_double), ALLOCATABLE, TARGET    :: lay(:, :, :), scal(:, :)
   INTEGER(c_int32_t), ALLOCATABLE, TARGET :: n_active(:)
   ! forcing tables (atmoflux_flag 2), mo_data.f90:166-171
-  INTEGER :: Length_Input = 13148
+  INTEGER :: Length_Input = 13148, nsites = 1
   REAL(c_double), ALLOCATABLE, TARGET :: fl_sw_input(:), fl_lw_input(:), T2m_input(:), precip_input(:)
   REAL(c_double), ALLOCATABLE, TARGET :: dT2m_col(:), precip_scale_col(:)
   CHARACTER*12000 :: format_T, format_psi, format_thick, format_snow, format_perm, format_melt
@@ -240,11 +241,22 @@ CONTAINS
 
   !> sub_input, mo_functions.f90:304-327: list-directed read of the four ERA-interim tables in the working directory
   SUBROUTINE sub_input()
-    ALLOCATE(fl_sw_input(Length_Input), fl_lw_input(Length_Input), T2m_input(Length_Input), precip_input(Length_Input))
-    OPEN(1234, file='flux_lw.txt.input', status='old'); READ(1234, *) fl_lw_input; CLOSE(1234)
-    OPEN(1234, file='flux_sw.txt.input', status='old'); READ(1234, *) fl_sw_input; CLOSE(1234)
-    OPEN(1234, file='T2m.txt.input', status='old');     READ(1234, *) T2m_input;   CLOSE(1234)
-    OPEN(1234, file='precip.txt.input', status='old');  READ(1234, *) precip_input; CLOSE(1234)
+    INTEGER :: s, n0
+    CHARACTER(len=300) :: dir
+    nsites = COUNT(LEN_TRIM(sites) > 0)
+    IF (nsites == 0) THEN            ! as the reference: the four files of the working directory
+       nsites = 1; sites(1) = '.'
+    END IF
+    ALLOCATE(fl_sw_input(Length_Input*nsites), fl_lw_input(Length_Input*nsites), T2m_input(Length_Input*nsites), &
+         precip_input(Length_Input*nsites))
+    DO s = 1, nsites
+       dir = TRIM(sites(s))//'/'
+       n0 = (s - 1)*Length_Input
+       OPEN(1234, file=TRIM(dir)//'flux_lw.txt.input', status='old'); READ(1234, *) fl_lw_input(n0+1:n0+Length_Input); CLOSE(1234)
+       OPEN(1234, file=TRIM(dir)//'flux_sw.txt.input', status='old'); READ(1234, *) fl_sw_input(n0+1:n0+Length_Input); CLOSE(1234)
+       OPEN(1234, file=TRIM(dir)//'T2m.txt.input', status='old');     READ(1234, *) T2m_input(n0+1:n0+Length_Input);   CLOSE(1234)
+       OPEN(1234, file=TRIM(dir)//'precip.txt.input', status='old');  READ(1234, *) precip_input(n0+1:n0+Length_Input); CLOSE(1234)
+    END DO
   END SUBROUTINE sub_input
 
   !> counter-based ensemble perturbation (SURVEY.md 8d cfg3): splitmix64(column_id xor 0x5A5A2026); column 0 unperturbed
@@ -542,7 +554,7 @@ CONTAINS
     TYPE(samsim_output_soa) :: o
     TYPE(samsim_clock)      :: clk
     REAL(c_double), ALLOCATABLE, TARGET :: olay(:, :, :), oscal(:, :), obgc(:, :, :), obot(:, :)
-    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: ona(:), status(:), err_layer(:)
+    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: ona(:), status(:), err_layer(:), site_of_column(:)
     INTEGER(c_int64_t), ALLOCATABLE :: err_step(:)
     INTEGER(c_int64_t) :: n, done, total, cells, colsteps
     INTEGER :: nfail, count0, count1, rate
@@ -556,13 +568,18 @@ CONTAINS
     CALL samsim_check(samsim_create(cfg, ncol, INT(device, c_int32_t), h), 'samsim_create')
     IF (cfg%atmoflux_flag == 2) THEN
        CALL sub_input()
+       ALLOCATE(site_of_column(ncol))
+       DO n = 1, ncol
+          site_of_column(n) = INT(MOD(n - 1, INT(nsites, c_int64_t)), c_int32_t)
+       END DO
        IF (perturb) THEN
           CALL sub_perturbation()
-          CALL samsim_check(samsim_set_forcing(h, INT(Length_Input, c_int32_t), fl_sw_input, fl_lw_input, T2m_input, &
-               precip_input, c_loc(dT2m_col), c_loc(precip_scale_col)), 'samsim_set_forcing')
+          CALL samsim_check(samsim_set_forcing_sites(h, INT(nsites, c_int32_t), INT(Length_Input, c_int32_t), fl_sw_input, &
+               fl_lw_input, T2m_input, precip_input, site_of_column, c_loc(dT2m_col), c_loc(precip_scale_col)), &
+               'samsim_set_forcing_sites')
        ELSE
-          CALL samsim_check(samsim_set_forcing(h, INT(Length_Input, c_int32_t), fl_sw_input, fl_lw_input, T2m_input, &
-               precip_input, c_null_ptr, c_null_ptr), 'samsim_set_forcing')
+          CALL samsim_check(samsim_set_forcing_sites(h, INT(nsites, c_int32_t), INT(Length_Input, c_int32_t), fl_sw_input, &
+               fl_lw_input, T2m_input, precip_input, site_of_column, c_null_ptr, c_null_ptr), 'samsim_set_forcing_sites')
        END IF
     END IF
     st%ncol = ncol; st%nlayer = cfg%nlayer; st%narr = SAMSIM_NARR
@@ -649,7 +666,7 @@ PROGRAM SAMSIM
   INTEGER         :: testcase, ios, nml_unit
   CHARACTER*12000 :: description
   LOGICAL         :: have_nml
-  NAMELIST /samsim_run/ testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out
+  NAMELIST /samsim_run/ testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out, sites
 
   testcase    = 1
   description = 'MI355X-native batched column solver'

@@ -145,6 +145,12 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
 int samsim_set_forcing(samsim_handle *h, int32_t len, const double *fl_sw, const double *fl_lw,
                        const double *T2m, const double *precip,
                        const double *dT2m_col, const double *precip_scale_col);
+/* Forcing for a grid of columns: nsites sets of the four tables (e.g. the nine ERA-interim sites
+ * under input/ERA-interim of the reference), each array holding set s at [s*len, (s+1)*len); site_of_column[c] in
+ * [0, nsites) selects the set column c reads.  samsim_set_forcing is the one-site case. */
+int samsim_set_forcing_sites(samsim_handle *h, int32_t nsites, int32_t len, const double *fl_sw, const double *fl_lw,
+                             const double *T2m, const double *precip, const int32_t *site_of_column,
+                             const double *dT2m_col, const double *precip_scale_col);
 
 /* initial state of init(testcase) (mo_init.f90:141-1978) or a checkpoint; col0 and s->ncol select a window.
  * The two perturbation slots SAMSIM_S_DT2M / SAMSIM_S_PRECIP_SCALE are owned by samsim_set_forcing: set_state

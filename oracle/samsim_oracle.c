@@ -1755,13 +1755,24 @@ static double *dupd(const double *p, int n) { double *q = (double *)malloc(sizeo
 
 int oracle_set_forcing(oracle_handle *h, int32_t len, const double *fl_sw, const double *fl_lw, const double *T2m,
                        const double *precip, const double *dT2m_col, const double *precip_scale_col) {
-  if (!h || len < 2 || !fl_sw || !fl_lw || !T2m || !precip) return SAMSIM_ERR_ARG;
+  return oracle_set_forcing_sites(h, 1, len, fl_sw, fl_lw, T2m, precip, NULL, dT2m_col, precip_scale_col);
+}
+
+/* mirror of samsim_set_forcing_sites: every column reads the tables of its own site */
+int oracle_set_forcing_sites(oracle_handle *h, int32_t nsites, int32_t len, const double *fl_sw, const double *fl_lw,
+                             const double *T2m, const double *precip, const int32_t *site_of_column,
+                             const double *dT2m_col, const double *precip_scale_col) {
+  if (!h || len < 2 || nsites < 1 || !fl_sw || !fl_lw || !T2m || !precip || (nsites > 1 && !site_of_column)) return SAMSIM_ERR_ARG;
   free(h->f_sw); free(h->f_lw); free(h->f_T2m); free(h->f_precip);
-  h->f_sw = dupd(fl_sw, len); h->f_lw = dupd(fl_lw, len); h->f_T2m = dupd(T2m, len); h->f_precip = dupd(precip, len);
+  h->f_sw = dupd(fl_sw, len * nsites); h->f_lw = dupd(fl_lw, len * nsites); h->f_T2m = dupd(T2m, len * nsites);
+  h->f_precip = dupd(precip, len * nsites);
   h->flen = len;
   for (int64_t i = 0; i < h->ncol; i++) {
     column *c = &h->cols[i];
-    c->flen = len; c->fl_sw_input = h->f_sw; c->fl_lw_input = h->f_lw; c->T2m_input = h->f_T2m; c->precip_input = h->f_precip;
+    size_t off = (nsites > 1) ? (size_t)site_of_column[i] * (size_t)len : 0;
+    if (nsites > 1 && (site_of_column[i] < 0 || site_of_column[i] >= nsites)) return SAMSIM_ERR_ARG;
+    c->flen = len; c->fl_sw_input = h->f_sw + off; c->fl_lw_input = h->f_lw + off; c->T2m_input = h->f_T2m + off;
+    c->precip_input = h->f_precip + off;
     c->dT2m = dT2m_col ? dT2m_col[i] : 0.0;
     c->precip_scale = precip_scale_col ? precip_scale_col[i] : 1.0;
   }

@@ -28,6 +28,9 @@ int  oracle_create(const samsim_config *cfg, int64_t ncol, oracle_handle **h);
 int  oracle_set_forcing(oracle_handle *h, int32_t len, const double *fl_sw, const double *fl_lw,
                         const double *T2m, const double *precip,
                         const double *dT2m_col, const double *precip_scale_col);
+int  oracle_set_forcing_sites(oracle_handle *h, int32_t nsites, int32_t len, const double *fl_sw, const double *fl_lw,
+                              const double *T2m, const double *precip, const int32_t *site_of_column,
+                              const double *dT2m_col, const double *precip_scale_col);
 int  oracle_set_state(oracle_handle *h, const samsim_state_soa *s, int64_t col0);
 int  oracle_get_state(oracle_handle *h, samsim_state_soa *s, int64_t col0);
 int  oracle_set_clock(oracle_handle *h, const samsim_clock *c);

@@ -185,6 +185,7 @@ class Solver:
         vp, i64, i32, dp = C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)
         sig = {
             "set_forcing": [vp, i32, dp, dp, dp, dp, dp, dp],
+            "set_forcing_sites": [vp, i32, i32, dp, dp, dp, dp, C.POINTER(C.c_int32), dp, dp],
             "set_state": [vp, C.POINTER(StateSoA), i64], "get_state": [vp, C.POINTER(StateSoA), i64],
             "set_clock": [vp, C.POINTER(Clock)], "get_clock": [vp, C.POINTER(Clock)],
             "step": [vp, i64], "set_output_window": [vp, i64, i64], "get_output": [vp, C.POINTER(OutputSoA)],
@@ -222,6 +223,19 @@ class Solver:
         self._chk(self._f("set_forcing")(self._h, n, *[_dp(a) for a in arrs],
                                          _dp(d) if d is not None else None, _dp(p) if p is not None else None),
                   "set_forcing")
+
+    def set_forcing_sites(self, fl_sw, fl_lw, T2m, precip, site_of_column, dT2m=None, precip_scale=None):
+        """tables [nsites][len] (samsim_set_forcing_sites): column c reads set site_of_column[c]"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (fl_sw, fl_lw, T2m, precip)]
+        nsites, n = arrs[0].shape
+        assert all(a.shape == (nsites, n) for a in arrs)
+        site = np.ascontiguousarray(site_of_column, dtype=np.int32)
+        assert site.shape == (self.ncol,)
+        d = None if dT2m is None else np.ascontiguousarray(dT2m, dtype=np.float64)
+        p = None if precip_scale is None else np.ascontiguousarray(precip_scale, dtype=np.float64)
+        self._chk(self._f("set_forcing_sites")(self._h, nsites, n, *[_dp(a) for a in arrs], _ip(site),
+                                               _dp(d) if d is not None else None, _dp(p) if p is not None else None),
+                  "set_forcing_sites")
 
     def set_state(self, st: State, col0: int = 0):
         s = st._c()

@@ -53,7 +53,8 @@ struct samsim_handle {
   int32_t n_bgc = 0;
   double bgc_total0 = 0.0;
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
-  int32_t flen = 0;
+  int32_t flen = 0, nsites = 1;
+  int32_t *site = nullptr;     // [ncol] forcing set of each column (nsites > 1)
   double *out_lay = nullptr, *out_scal = nullptr;
   int32_t *out_n_active = nullptr;
   long long out_col0 = 0, out_ncols = 0;
@@ -201,6 +202,7 @@ int launch(samsim_handle *h, long long nsteps) {
   p.err_step = h->err_step; p.work = h->work;
   p.spec = h->spec; p.flags = h->flags;
   p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
+  p.nsites = h->nsites; p.site = h->site;
   p.ncol = h->ncol;
   p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
   p.nsteps = nsteps;
@@ -313,7 +315,7 @@ void samsim_destroy(samsim_handle *h) {
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
   (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat);
   (void)hipFree(h->bgc); (void)hipFree(h->bgc_bot); (void)hipFree(h->bfl); (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
-  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
+  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip); (void)hipFree(h->site);
   (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
   (void)hipFree(h->d_params);
   if (h->h_params) (void)hipHostFree(h->h_params);
@@ -326,15 +328,28 @@ void samsim_destroy(samsim_handle *h) {
 
 int samsim_set_forcing(samsim_handle *h, int32_t len, const double *fl_sw, const double *fl_lw, const double *T2m,
                        const double *precip, const double *dT2m_col, const double *precip_scale_col) {
+  return samsim_set_forcing_sites(h, 1, len, fl_sw, fl_lw, T2m, precip, nullptr, dT2m_col, precip_scale_col);
+}
+
+int samsim_set_forcing_sites(samsim_handle *h, int32_t nsites, int32_t len, const double *fl_sw, const double *fl_lw,
+                             const double *T2m, const double *precip, const int32_t *site_of_column,
+                             const double *dT2m_col, const double *precip_scale_col) {
   int rc = use(h);
   if (rc) return rc;
-  if (len < 2 || !fl_sw || !fl_lw || !T2m || !precip) return SAMSIM_ERR_ARG;
+  if (len < 2 || nsites < 1 || !fl_sw || !fl_lw || !T2m || !precip || (nsites > 1 && !site_of_column)) return SAMSIM_ERR_ARG;
+  for (long long c = 0; nsites > 1 && c < h->ncol; ++c)
+    if (site_of_column[c] < 0 || site_of_column[c] >= nsites) return SAMSIM_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
-  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip);
-  h->f_sw = h->f_lw = h->f_T2m = h->f_precip = nullptr;
-  const size_t bytes = sizeof(double) * (size_t)len;
-  HIPCHK(dalloc(&h->f_sw, (size_t)len)); HIPCHK(dalloc(&h->f_lw, (size_t)len));
-  HIPCHK(dalloc(&h->f_T2m, (size_t)len)); HIPCHK(dalloc(&h->f_precip, (size_t)len));
+  (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip); (void)hipFree(h->site);
+  h->f_sw = h->f_lw = h->f_T2m = h->f_precip = nullptr; h->site = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)len * (size_t)nsites;
+  HIPCHK(dalloc(&h->f_sw, (size_t)len * nsites)); HIPCHK(dalloc(&h->f_lw, (size_t)len * nsites));
+  HIPCHK(dalloc(&h->f_T2m, (size_t)len * nsites)); HIPCHK(dalloc(&h->f_precip, (size_t)len * nsites));
+  h->nsites = nsites;
+  if (nsites > 1) {
+    HIPCHK(dalloc(&h->site, (size_t)h->ncol));
+    HIPCHK(hipMemcpy(h->site, site_of_column, sizeof(int32_t) * (size_t)h->ncol, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpy(h->f_sw, fl_sw, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->f_lw, fl_lw, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->f_T2m, T2m, bytes, hipMemcpyHostToDevice));

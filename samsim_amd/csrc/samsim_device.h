@@ -54,6 +54,8 @@ struct DevParams {
   int32_t *flags;       // [ncol] COLF_*
   const double *f_sw, *f_lw, *f_T2m, *f_precip;
   int32_t flen;
+  int32_t nsites;               // forcing sets; table s starts at s*flen
+  const int32_t *site;          // [ncol] set of each column (nsites > 1)
   long long ncol;
   // uniform clock at launch (mo_data: time, i, n_time_out, time_counter)
   double time0;

@@ -324,6 +324,7 @@ struct Ctx {
   double S_bu_bottom;
   // passive tracers (bgc_flag 2, KGeneric only): amounts [n_bgc][N][ncol], concentration below the ice [n_bgc][ncol], this
   // step's brine fluxes [BFL_NROW][N][ncol], snapshot of the output window
+  int soff;   // start of this column's forcing set in the tables (0 unless samsim_set_forcing_sites gave several)
   gdouble *bgc, *bgc_bot, *bfl, *out_bgc, *out_bgc_bot;
   int n_bgc;
   double bgc_total0;
@@ -1190,12 +1191,12 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
   c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, CFG(albedo_flag));
   if (!K::general || CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
-      c.fl_sw = x.f_sw[tc - 1];
-      c.fl_lw = x.f_lw[tc - 1];
+      c.fl_sw = x.f_sw[x.soff + tc - 1];
+      c.fl_lw = x.f_lw[x.soff + tc - 1];
     } else {
       const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-      c.fl_sw = (1.0 - temp) * x.f_sw[tc - 2] + temp * x.f_sw[tc - 1];
-      c.fl_lw = (1.0 - temp) * x.f_lw[tc - 2] + temp * x.f_lw[tc - 1];
+      c.fl_sw = (1.0 - temp) * x.f_sw[x.soff + tc - 2] + temp * x.f_sw[x.soff + tc - 1];
+      c.fl_lw = (1.0 - temp) * x.f_lw[x.soff + tc - 2] + temp * x.f_lw[x.soff + tc - 1];
     }
   } else if (CFG(atmoflux_flag) == 1) {
     // sub_notzflux(time + 180 days), mo_functions.f90:270-289 (47.9, 53.1 are default-REAL literals); fl_rest lives in
@@ -1994,12 +1995,12 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // forcing, mo_grotz.f90:229-241 (+ ensemble perturbation)
   if (CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
-      c.T2m = x.f_T2m[tc - 1];
-      c.liquid_precip = x.f_precip[tc - 1];
+      c.T2m = x.f_T2m[x.soff + tc - 1];
+      c.liquid_precip = x.f_precip[x.soff + tc - 1];
     } else {
       const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-      c.T2m = (1.0 - temp) * x.f_T2m[tc - 2] + temp * x.f_T2m[tc - 1];
-      c.liquid_precip = (1.0 - temp) * x.f_precip[tc - 2] + temp * x.f_precip[tc - 1];
+      c.T2m = (1.0 - temp) * x.f_T2m[x.soff + tc - 2] + temp * x.f_T2m[x.soff + tc - 1];
+      c.liquid_precip = (1.0 - temp) * x.f_precip[x.soff + tc - 2] + temp * x.f_precip[x.soff + tc - 1];
     }
     c.T2m = c.T2m + c.dT2m;
     c.liquid_precip = c.liquid_precip * c.precip_scale;
@@ -2217,7 +2218,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
                                                                         double *__restrict__ out_scal, int32_t *__restrict__ out_n_active,
                                                                         double *__restrict__ bgc, double *__restrict__ bgc_bot,
                                                                         double *__restrict__ bfl, double *__restrict__ out_bgc,
-                                                                        double *__restrict__ out_bgc_bot) {
+                                                                        double *__restrict__ out_bgc_bot, const int32_t *__restrict__ site) {
   const DevParams &p = *pp;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= p.ncol) return;
@@ -2229,6 +2230,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.bgc = (gdouble *)bgc; x.bgc_bot = (gdouble *)bgc_bot; x.bfl = (gdouble *)bfl;
   x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
   x.n_bgc = K::general ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
+  x.soff = (K::general && p.nsites > 1) ? site[col] * p.flen : 0;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   x.S_bu_bottom = (K::general && (K::fixed ? K::tank_flag : p.cfg.tank_flag) == 2) ? scal[(size_t)SAMSIM_S_S_BU_BOTTOM * (size_t)p.ncol + (size_t)col] : p.cfg.S_bu_bottom;
@@ -2319,12 +2321,12 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
-  const bool tracers = g.bgc_flag == 2;   // tracer code exists in the run-time-flag instantiation only
+  const bool tracers = g.bgc_flag == 2 || hp->nsites > 1;   // tracers and per-column forcing sets exist in the run-time-flag instantiation only
   auto kernel = (!tracers && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
                 : (!tracers && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
                      hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active, hp->bgc, hp->bgc_bot, hp->bfl, hp->out_bgc,
-                     hp->out_bgc_bot);
+                     hp->out_bgc_bot, hp->site);
   return hipGetLastError();
 }

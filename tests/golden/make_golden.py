@@ -21,6 +21,8 @@ Fixtures are DATA only -- inputs and expected outputs:
   tc{1,2,6}_bgc_ref.npz     the passive tracers of the testcases that ship with bgc_flag 2: bgc_abs and bgc_bottom at every
                             output point (float64); the committed dat_bgc0{1,2}.{bu,br}.dat of testcase 1 are in
                             tc1_reference_dat.npz
+  era_sites_forcing.npz /   the tables of three more ERA-interim sites of the reference (North Pole, Barrow, 70N00W) and the
+  tc4_northpole_ref.npz     first 150 output days of testcase 4 run by the reference on the North Pole tables
   tc7_ref_fullprec.npz      testcase 7 (SHEBA with the simple parametrisations): scalars of the first 131 output points (the
                             reference's fl_grav_drain_simple reads an uninitialised local, so its own trajectory depends on
                             stack history), layers at selected ones, and teacher-forcing pairs through the first
@@ -164,6 +166,29 @@ def main():
         for k, v in pack(recs, with_layers=False).items():
             d["all_" + k] = v
         np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
+    # --- forcing of other ERA-interim sites: three more sets of tables, and the reference on the North Pole set
+    d = {}
+    for site in ("NorthPole-p2", "barrow-p2", "70N00W-p2"):
+        for n, a in zip(("fl_sw", "fl_lw", "T2m", "precip"), tcs.read_forcing(os.path.join(REF, "input", "ERA-interim", site))):
+            d[site.replace("-p2", "") + "_" + n] = a
+    np.savez_compressed(os.path.join(OUT, "era_sites_forcing.npz"), **d)
+    run_np = os.path.join(ROOT, "oracle", "_ref", "run_np")
+    os.makedirs(os.path.join(run_np, "output"), exist_ok=True)
+    for n in ("flux_lw", "flux_sw", "T2m", "precip"):
+        dst = os.path.join(run_np, n + ".txt.input")
+        if not os.path.lexists(dst):
+            os.symlink(os.path.join(REF, "input", "ERA-interim", "NorthPole-p2", n + ".txt.input"), dst)
+    if not os.path.exists(os.path.join(run_np, "tc4_np.bin")):
+        subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "samsim_ref_dump"), "4"], cwd=run_np, stdout=subprocess.DEVNULL,
+                              env=dict(os.environ, SAMSIM_REF_DUMP="tc4_np.bin", SAMSIM_REF_MAXSTEPS="1300000"))
+    recs = read_dump(os.path.join(run_np, "tc4_np.bin"))
+    sel = [0, 30, 60, 100, 140]
+    d = pack([recs[i] for i in sel])
+    d["index"] = np.array(sel)
+    for k, v in pack(recs, with_layers=False).items():
+        d["all_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "tc4_northpole_ref.npz"), **d)
+
     # --- tracers (bgc on, as init(1), init(2), init(6) ship): bgc_abs and bgc_bottom at every output point
     for tc in (1, 2, 6):
         cached(tc, f"tc{tc}_bgc.bin")

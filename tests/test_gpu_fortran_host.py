@@ -114,3 +114,22 @@ def test_fortran_host_tank_experiment(tmp_path):
         assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc9 output {i}"
     s = (tmp_path / "output" / "dat_settings.dat").read_text()
     assert "tank_flag               2" in s and "boundflux_flag          3" in s
+
+
+@pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")
+def test_fortran_host_grid_of_sites(tmp_path):
+    """`sites` in &samsim_run: columns spread over two directories of forcing tables; column 2 (North Pole tables) prints the
+    reference's own North Pole run, column 1 the SHEBA run"""
+    z = golden("era_sites_forcing.npz")
+    for d, pre in (("np", "NorthPole_"),):
+        (tmp_path / d).mkdir()
+        for key, name in (("fl_sw", "flux_sw"), ("fl_lw", "flux_lw"), ("T2m", "T2m"), ("precip", "precip")):
+            np.savetxt(tmp_path / d / f"{name}.txt.input", z[pre + key], fmt="%.17e")
+    out = run_host(tmp_path, "&samsim_run testcase=4, ncol=4, out_col=2, max_steps=60000, sites='.', 'np' /\n")
+    assert "SAMSIM is finished" in out
+    ref = golden("tc4_northpole_ref.npz")
+    vs = load(tmp_path, "vital_signs")                 # energy_stored, freshwater, total_resist, thickness, bulk_salin
+    assert vs.shape[0] == 7
+    assert np.abs(vs[:, 3] - np.round(ref["all_s_thickness"][:7], 5)).max() <= 2e-5
+    T2 = np.loadtxt(tmp_path / "output" / "dat_T2m_T_top.dat")
+    assert np.abs(T2[:, 0] - np.round(ref["all_s_T2m"][:7], 3)).max() <= 1.5e-3

@@ -191,3 +191,38 @@ def test_flood_simple_under_heavy_snow():
         o.step(n)
         sg, so = _check(g, o, f"flood_simple +{n}")
     assert so.sc("thick_snow").max() < snow0 - 0.05, "flood_simple did not fire"
+
+
+def test_grid_of_columns_on_four_forcing_sites():
+    """samsim_set_forcing_sites: 64 perturbed columns spread over the SHEBA, North Pole, Barrow and 70N00W
+    tables; free run from open water through freeze-up against the oracle (every column reads its own tables), and the
+    snapshots of an unperturbed North Pole column against the reference's own run on those tables"""
+    sites = ["NorthPole", "barrow", "70N00W"]
+    z = golden("era_sites_forcing.npz")
+    sheba = sheba_forcing()
+    tables = [np.stack([sheba[i]] + [z[f"{s}_{n}"] for s in sites]) for i, n in enumerate(("fl_sw", "fl_lw", "T2m", "precip"))]
+    ncol = 64
+    site = (np.arange(ncol) % 4).astype(np.int32)
+    dT, ps = tcs.ensemble_perturbation(ncol)
+    dT[1], ps[1] = 0.0, 1.0                               # column 1 = the North Pole member as the reference runs it
+    cfg, st = tcs.testcase4(ncol)
+    g, o = samsim_amd.hip_solver(cfg, ncol), oracle_solver(cfg, ncol)
+    o.set_threads(NTHREADS)
+    for s in (g, o):
+        s.set_forcing_sites(*tables, site, dT, ps)
+        s.set_state(st)
+        s.set_clock()
+    g.set_output_window(1, 1)
+    ref = golden("tc4_northpole_ref.npz")
+    for i in range(6):
+        out = g.run_to_output()
+        assert out.step == ref["all_step"][i] and out.n_active[0] == ref["all_N_active"][i]
+        for n, floor in (("T2m", 1e-2), ("T_top", 1e-2), ("thickness", 1e-7), ("thick_snow", 1e-7), ("bulk_salin", 1e-5)):
+            assert rel_err(out.sc(n)[0], ref["all_s_" + n][i], floor) <= RTOL, f"north pole output {i}: {n}"
+    o.step(g.get_clock().step)
+    sg, so = _check(g, o, "four sites, day 5")
+    g.step(30000)
+    o.step(30000)
+    sg, so = _check(g, o, "four sites, +30000")
+    T2m = so.sc("T2m")
+    assert len({round(float(T2m[site == k].mean()), 3) for k in range(4)}) == 4      # the four sites really differ

@@ -218,6 +218,22 @@ def test_tank_experiments_bitwise(tc, nout):
     assert ref["all_s_S_bu_bottom"].max() > cfg.S_bu_bottom + 0.2 and not o.get_status()[0].any()
 
 
+def test_tc4_on_north_pole_forcing_bitwise():
+    """testcase 4 physics on another ERA-interim site of the reference (input/ERA-interim/NorthPole-p2):
+    first 150 output days against the flang-built reference run in a directory that holds those tables"""
+    cfg, st = tcs.testcase4(1)
+    z = golden("era_sites_forcing.npz")
+    o = oracle_solver(cfg, 1)
+    o.set_forcing(*[z["NorthPole_" + n] for n in ("fl_sw", "fl_lw", "T2m", "precip")])
+    o.set_state(st)
+    o.set_clock()
+    ref = golden("tc4_northpole_ref.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    for i in range(len(ref["all_step"])):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"north pole day {i + 1}", layers=LAYERS)
+    assert not o.get_status()[0].any()
+
+
 def bgc_bu_br(bgc_abs, bgc_bottom, m, psi_l, thick, na):
     """output_bgc, mo_output.f90:156-188: the bulk and brine concentrations the reference prints per tracer"""
     nb, nl = bgc_abs.shape
