@@ -2050,6 +2050,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       store_psi = next_out || last_step || e1.psi_s < psi_s_top_min + 0.05 || T_top_est >= T_fr - 1.0 ||
                   (c.thick_snow > 0.0 && (c.T_snow > -8.0 || c.melt_thick_snow > 0.0));
     }
+    // without melt-water flushing (flush_flag 1) nothing on the fused path reads them but the vital signs and get_state
+    if (K::fixed && K::flush_flag == 1) store_psi = next_out || last_step;
     c.psi_full = store_psi;
     sweep_down_fused<K>(c, x, do_beer, beer0, store_psi);
     if (c.status) return;
