@@ -216,12 +216,19 @@ def test_failed_columns_are_frozen_and_reported():
 
 
 def test_unsupported_flags_are_rejected():
-    for flag, value in (("prescribe_flag", 2), ("flush_flag", 6), ("bgc_flag", 2), ("lab_snow_flag", 1)):
+    for flag, value in (("prescribe_flag", 2), ("flush_flag", 6), ("lab_snow_flag", 1)):
         cfg, _ = tcs.testcase2(1) if flag == "lab_snow_flag" else tcs.testcase1(1)
         setattr(cfg, flag, value)
         with pytest.raises(samsim_amd.SamsimError) as e:
             samsim_amd.hip_solver(cfg, 4)
         assert e.value.code == -2, flag
+    cfg, st = tcs.testcase1(4)
+    cfg.bgc_flag = 2                     # tracers on, but samsim_set_tracers not called: the step is refused
+    g = samsim_amd.hip_solver(cfg, 4)
+    g.set_state(st)
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        g.step(1)
+    assert e.value.code == -1
     cfg, _ = tcs.testcase1(1)
     cfg.struct_size = 8
     with pytest.raises(samsim_amd.SamsimError) as e:
