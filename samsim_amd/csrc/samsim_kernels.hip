@@ -256,6 +256,19 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
   return rc;
 }
 
+// The solid fraction getT returned for a layer, recomputed from the temperature it returned and the values it was called
+// with (mo_thermo_functions.f90:84,129,131-143): same operands, same operations, so the same phi bit for bit.  The down sweeps
+// use it instead of loading phi (one array less to hand over).
+__device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_bu, double S_br_T) {
+  if (S_br_clamped(s, H / c_l, S_bu) > S_bu && S_bu > 0.001) return 1.0 - S_bu / S_br_T;
+  if (S_bu < 0.001) {
+    if (H > 0.0) return 0.0;
+    if (H <= -latent_heat) return 1.0;
+    return -H / latent_heat;
+  }
+  return 0.0;
+}
+
 // x**3.10 of the permeability law (mo_grav_drain.f90:105, mo_flush.f90:119,128, mo_flood.f90:73) as exp(3.1*log(x)):
 // within ~4e-15 relative of the correctly rounded pow() the reference links (|3.1*log x| <= 22 for x <= 1000), at a
 // third of its instructions and without the double-double constant tables that push the layer loops into spills.
@@ -701,7 +714,13 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     double m = LAY(SAMSIM_A_M, k);
     const double thick = LAY(SAMSIM_A_THICK, k);
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
-    const Expelled ex = expulsion(LAY(SAMSIM_A_PHI, k), thick, m);
+    const double T = LAY(SAMSIM_A_T, k), H_abs_in = LAY(SAMSIM_A_H_ABS, k);
+    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const double S_bu_in = per_mass(S_abs, m);
+    // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
+    // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
+    const double S_br = S_br_clamped(x.salt, T, S_bu_in);
+    const Expelled ex = expulsion(phi_from_T(x.salt, H_abs_in / m, S_bu_in, S_br), thick, m);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g;
     double flm_next;
@@ -716,20 +735,13 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
     LAY(SAMSIM_A_PSI_G, k) = psi_g;
     if (k >= 2) LAY(D_HR, k) = thick / (2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));  // hand-over to the up sweep
-    const double m_in = m;
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
     if (HAS_BGC) BFL(BFL_E, k) = transfer ? -flm_next : 0.0;
-    double S_abs = LAY(SAMSIM_A_S_ABS, k);
-    // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
-    // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
-    const double T = LAY(SAMSIM_A_T, k);
-    const double S_br = S_br_clamped(x.salt, T, per_mass(S_abs, m_in));
     LAY(SAMSIM_A_S_BR, k) = S_br;
     if (transfer) {
-      double H_abs = 0.0;
+      double H_abs = H_abs_in;
       bool ch = false;
-      if (flm_next < 0.0 || flm_k < 0.0) H_abs = LAY(SAMSIM_A_H_ABS, k);
       if (flm_next < 0.0) {
         H_abs = H_abs + flm_next * T * c_l;
         S_abs = S_abs + dmax(flm_next * S_br, -S_abs);
@@ -1045,13 +1057,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
   int stop_layer = 0;
 
-  struct Raw { double T, S_abs, m, S_br; };
+  struct Raw { double T, S_abs, m, S_bu, S_br; };
   auto load_raw = [&](int j) -> Raw {
     Raw r;
     r.T = LAY(SAMSIM_A_T, j);
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.m = LAY(SAMSIM_A_M, j);
-    r.S_br = S_br_clamped(s, r.T, per_mass(r.S_abs, r.m));  // S_br(j) of the first sweep
+    r.S_bu = per_mass(r.S_abs, r.m);
+    r.S_br = S_br_clamped(s, r.T, r.S_bu);  // S_br(j) of the first sweep
     return r;
   };
   struct Lay { double T, S_bu, S_abs, H_abs, m, flup; };
@@ -1068,9 +1081,10 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     // ---- A(j)
     const double thick = LAY(SAMSIM_A_THICK, j);
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
-    const Expelled ex = expulsion(LAY(SAMSIM_A_PHI, j), thick, raw.m);
+    double H_abs = LAY(SAMSIM_A_H_ABS, j);
+    const Expelled ex = expulsion(phi_from_T(s, H_abs / raw.m, raw.S_bu, raw.S_br), thick, raw.m);
     const double V_ex = ex.V_ex;
-    double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs, H_abs = LAY(SAMSIM_A_H_ABS, j);
+    double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
     if (do_beer) {
       if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
@@ -1298,7 +1312,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
 // regrid trigger all act on it between the two steps.  If flushing or a regrid changes deeper layers afterwards, the
 // column is flagged COLF_DIRTY and the next step runs the full first sweep instead.
 template <class K>
-__device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output) {
+__device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long col, bool next_is_output, bool store_phi) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -1365,7 +1379,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
     LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_PHI, k) = phi;   // = phi of the next step's first sweep for k >= 2: the hand-over to the next down sweep
+    // the down sweeps recompute phi from T; the array is kept for its readers: the regrid trigger and layer_dynamics (bottom
+    // two active layers), layer 1, the output snapshot and get_state
+    if (store_phi || k == 1 || k >= Na - 1) LAY(SAMSIM_A_PHI, k) = phi;
     if (k > 1) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
       double S_bu_n = S_bu;
@@ -2076,7 +2092,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
   surface_flux<K>(c, x);
-  sweep_up_fused<K>(c, x, col, next_out);
+  sweep_up_fused<K>(c, x, col, next_out, next_out || last_step);
   if (c.status) return;
 
   // snow thermodynamics again, mo_grotz.f90:603-625
