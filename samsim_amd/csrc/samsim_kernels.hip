@@ -1057,31 +1057,48 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
   int stop_layer = 0;
 
-  struct Raw { double T, S_abs, m, S_bu, S_br; };
-  auto load_raw = [&](int j) -> Raw {
-    Raw r;
+  // The sweeps are latency bound (a wave waits on memory for most of its life), so the loads run ahead of the arithmetic:
+  // the six values of layer j+2 are requested at the top of iteration j and first touched in iteration j+1 (S_br of the
+  // layer below is needed one layer early), which puts a full iteration of work between request and use.  Measured on the
+  // default bench: loads at use 82.3 ms per launch, one layer ahead 76.0, two ahead at 3 waves/SIMD 73.8 (two ahead at
+  // 4 waves/SIMD spills inside the loop: 93).
+  struct Ld { double T, S_abs, m, H_abs, thick, ray; };
+  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray; };
+  auto load_ld = [&](int j) -> Ld {
+    Ld r;
     r.T = LAY(SAMSIM_A_T, j);
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.m = LAY(SAMSIM_A_M, j);
+    r.H_abs = LAY(SAMSIM_A_H_ABS, j);
+    r.thick = LAY(SAMSIM_A_THICK, j);
+    r.ray = (j <= Na - 1) ? LAY(SAMSIM_A_RAY, j) : 0.0;
+    return r;
+  };
+  auto finish = [&](const Ld &l) -> Raw {
+    Raw r;
+    r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.thick = l.thick; r.ray = l.ray;
     r.S_bu = per_mass(r.S_abs, r.m);
-    r.S_br = S_br_clamped(s, r.T, r.S_bu);  // S_br(j) of the first sweep
+    r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
   };
   struct Lay { double T, S_bu, S_abs, H_abs, m, flup; };
 
   double flm_j = 0.0;                                  // fl_m(j) of expulsion_flux
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
-  Raw raw = load_raw(1), raw_n = raw;
+  Ld ahead = load_ld(1);
+  Raw raw = finish(ahead), raw_n = raw;
+  if (Na >= 2) ahead = load_ld(2);
   Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
   const int jmax = wave_max(Na);
   for (int j = 1; j <= jmax; ++j) {
     if (j > Na) continue;
-    if (j < Na) raw_n = load_raw(j + 1);
+    if (j < Na) raw_n = finish(ahead);
+    if (j + 2 <= Na) ahead = load_ld(j + 2);
     // ---- A(j)
-    const double thick = LAY(SAMSIM_A_THICK, j);
+    const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
-    double H_abs = LAY(SAMSIM_A_H_ABS, j);
+    double H_abs = raw.H_abs;
     const Expelled ex = expulsion(phi_from_T(s, H_abs / raw.m, raw.S_bu, raw.S_br), thick, raw.m);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
@@ -1135,7 +1152,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     sum_before += S_abs;
     double flup = cum;
     if (j <= Na - 1) {
-      const double ray = LAY(SAMSIM_A_RAY, j);
+      const double ray = raw.ray;
       if (ray > ray_crit && S_br > raw_n.S_br) {
         const double psi_s = ex.psi_s;
         if (psi_s > 0.001 && S_abs / m > 0.1) {
@@ -1340,24 +1357,28 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // layer 1 forms it here, because flooding and snow-ice formation change thick(1) between the two sweeps.
   const double hr_top = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
   double hr_k = (Na >= 2) ? LAY(D_HR, Na) : hr_top;
+  // H_abs, m, S_abs of layer k are loaded one iteration ahead, together with T, thick and the half resistance of layer k-1
+  // that the stencil needs now: a whole iteration of arithmetic hides their latency
+  double H_k = LAY(SAMSIM_A_H_ABS, Na), m_k = LAY(SAMSIM_A_M, Na), S_k = LAY(SAMSIM_A_S_ABS, Na);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
-    double flq_k, T_u = 0.0, th_u = 0.0, hr_u = 0.0;
+    double flq_k, T_u = 0.0, th_u = 0.0, hr_u = 0.0, H_u = 0.0, m_u = 0.0, S_u = 0.0;
     if (k > 1) {
       T_u = LAY(SAMSIM_A_T, k - 1);
       th_u = LAY(SAMSIM_A_THICK, k - 1);
       hr_u = (k > 2) ? LAY(D_HR, k - 1) : hr_top;
+      H_u = LAY(SAMSIM_A_H_ABS, k - 1); m_u = LAY(SAMSIM_A_M, k - 1); S_u = LAY(SAMSIM_A_S_ABS, k - 1);
       const double R = hr_u + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = (T_k - T_u) / R;
     } else {
       flq_k = c.fl_Q1;
     }
-    double H_abs = LAY(SAMSIM_A_H_ABS, k);
+    double H_abs = H_k;
     sum_before += H_abs;
     H_abs = H_abs + (flq_below - flq_k) * dt;
     H_abs = H_abs + c.frad * dt;
-    const double m = LAY(SAMSIM_A_M, k);
+    const double m = m_k;
     if (k == 1) {  // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
         c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
@@ -1371,7 +1392,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     }
     sum_after += H_abs;
     LAY(SAMSIM_A_H_ABS, k) = H_abs;
-    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    double S_abs = S_k;
     double S_bu, H;
     per_mass(S_abs, H_abs, m, S_bu, H);
     double T, phi = 0.0;
@@ -1392,7 +1413,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
     }
     flq_below = flq_k;
-    T_k = T_u; th_k = th_u; hr_k = hr_u;
+    T_k = T_u; th_k = th_u; hr_k = hr_u; H_k = H_u; m_k = m_u; S_k = S_u;
   }
   // hand-over block for prologue_top_layer of the next step
   c.spec[SP_MINP * nc] = r.minp; c.spec[SP_STP * nc] = r.stp; c.spec[SP_ST * nc] = r.st;
