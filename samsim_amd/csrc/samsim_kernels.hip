@@ -646,11 +646,14 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
+  // loads one layer ahead of the arithmetic, as in the fused sweeps
+  double H_n = LAY(SAMSIM_A_H_ABS, Na), m_n = LAY(SAMSIM_A_M, Na), th_n = LAY(SAMSIM_A_THICK, Na), S_n = LAY(SAMSIM_A_S_ABS, Na);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
-    const double H_abs = LAY(SAMSIM_A_H_ABS, k), m = LAY(SAMSIM_A_M, k), thick = LAY(SAMSIM_A_THICK, k);
-    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const double H_abs = H_n, m = m_n, thick = th_n;
+    double S_abs = S_n;
+    if (k > 1) { H_n = LAY(SAMSIM_A_H_ABS, k - 1); m_n = LAY(SAMSIM_A_M, k - 1); th_n = LAY(SAMSIM_A_THICK, k - 1); S_n = LAY(SAMSIM_A_S_ABS, k - 1); }
     if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
       S_abs = 0.0;
       LAY(SAMSIM_A_S_ABS, k) = S_abs;
@@ -710,12 +713,19 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   double flm_k = 0.0;  // fl_m(k)
   double buoy_g = 0.0;
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
+  // loads one layer ahead of the arithmetic, as in the fused sweeps
+  double m_n = LAY(SAMSIM_A_M, 1), th_n = LAY(SAMSIM_A_THICK, 1), T_n = LAY(SAMSIM_A_T, 1), H_n = LAY(SAMSIM_A_H_ABS, 1),
+         S_n = LAY(SAMSIM_A_S_ABS, 1);
   for (int k = 1; k <= Na; ++k) {
-    double m = LAY(SAMSIM_A_M, k);
-    const double thick = LAY(SAMSIM_A_THICK, k);
+    double m = m_n;
+    const double thick = th_n;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
-    const double T = LAY(SAMSIM_A_T, k), H_abs_in = LAY(SAMSIM_A_H_ABS, k);
-    double S_abs = LAY(SAMSIM_A_S_ABS, k);
+    const double T = T_n, H_abs_in = H_n;
+    double S_abs = S_n;
+    if (k < Na) {
+      m_n = LAY(SAMSIM_A_M, k + 1); th_n = LAY(SAMSIM_A_THICK, k + 1); T_n = LAY(SAMSIM_A_T, k + 1);
+      H_n = LAY(SAMSIM_A_H_ABS, k + 1); S_n = LAY(SAMSIM_A_S_ABS, k + 1);
+    }
     const double S_bu_in = per_mass(S_abs, m);
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
     // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
