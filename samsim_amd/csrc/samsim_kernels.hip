@@ -146,6 +146,14 @@ struct Col {
 // Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
 // bottom-up loops that run from the wave maximum of N_active); the lane only adds its 32-bit column offset, which lets
 // the compiler use scalar-base addressing (global_load ... v_off, s[base]) instead of a 64-bit VGPR address per array.
+// SAMSIM_FAST_DIV: quotients that share a divisor are formed through one reciprocal (Expulsion: /thick three times and the two
+// density constants; getT: /S_br and /S_br**2; S_abs/m and H_abs/m; H/c_l; the constant kappa_l*mu), each within 1-2 ulp of the
+// quotient the reference forms -- the parity bar is 1e-6 relative.  With the loads pipelined the sweeps are bound by their
+// dependent FP64 chains, and an IEEE division is an 11-instruction chain: 67.5 ms per launch of the default bench with the
+// shared reciprocals, 73.1 ms with the reference's quotients (=0).
+#ifndef SAMSIM_FAST_DIV
+#define SAMSIM_FAST_DIV 1
+#endif
 #ifndef LAY
 #define LAY(a, k) (c.lay + ((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 #endif
@@ -178,12 +186,16 @@ __device__ __forceinline__ int wave_max(int v) {
 
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
-// S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594.  (Forming them, Expulsion's quotients and the
-// Newton terms through shared reciprocals removes a third of the FP64 divisions and changes nothing in the launch time:
-// the sweeps wait on memory, not on the VALU.  The reference's quotients are kept.)
+// S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594
 __device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
+#if SAMSIM_FAST_DIV
+  const double rm = 1.0 / m;
+  S_bu = S_abs * rm;
+  H = H_abs * rm;
+#else
   S_bu = S_abs / m;
   H = H_abs / m;
+#endif
 }
 __device__ __forceinline__ double per_mass(double S_abs, double m) { return S_abs / m; }
 
@@ -206,14 +218,31 @@ __device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
 // clamps S_br at 1e-9, the ones in the loop at 1e-10, as in the reference)
 __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_bu, double T_0, double sb, double sb_floor,
                                              double &f, double &ddT_f) {
+#if SAMSIM_FAST_DIV
+  if (sb > 0.0001) {  // neither clamp is active: one reciprocal serves both quotients
+    const double inv = 1.0 / sb;
+    f = -latent_heat - H + latent_heat * S_bu * inv + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
+    ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) * (inv * inv);
+    return;
+  }
+#endif
   f = -latent_heat - H + latent_heat * S_bu / dmax(sb, sb_floor) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
   ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
+}
+
+// H/c_l: the temperature of pure brine of enthalpy H (first line of getT, mo_thermo_functions.f90:84)
+__device__ __forceinline__ double T_liquid(double H) {
+#if SAMSIM_FAST_DIV
+  return H * (1.0 / c_l);
+#else
+  return H / c_l;
+#endif
 }
 
 // getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
 // Returns 99 (the reference's STOP code) when 260 iterations do not converge.
 __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out) {
-  double T = H / c_l, phi = phi_out;
+  double T = T_liquid(H), phi = phi_out;
   int rc = 0;
   if (S_br_clamped(s, T, S_bu) > S_bu && S_bu > 0.001) {
     double T_fr = 0.0, T_0, f, ddT_f, sb;
@@ -260,7 +289,7 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
 // with (mo_thermo_functions.f90:84,129,131-143): same operands, same operations, so the same phi bit for bit.  The down sweeps
 // use it instead of loading phi (one array less to hand over).
 __device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_bu, double S_br_T) {
-  if (S_br_clamped(s, H / c_l, S_bu) > S_bu && S_bu > 0.001) return 1.0 - S_bu / S_br_T;
+  if (S_br_clamped(s, T_liquid(H), S_bu) > S_bu && S_bu > 0.001) return 1.0 - S_bu / S_br_T;
   if (S_bu < 0.001) {
     if (H > 0.0) return 0.0;
     if (H <= -latent_heat) return 1.0;
@@ -586,11 +615,19 @@ __device__ __forceinline__ void ray_scan_init(RayScan &r) {
 struct Expelled { double psi_s, psi_l, psi_g, V_ex; };
 __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m) {
   Expelled e;
+#if SAMSIM_FAST_DIV
+  const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l), rth = 1.0 / thick;
+  e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
+  e.psi_s = V_s * rth;
+  e.psi_l = (V_l - e.V_ex) * rth;
+  e.psi_g = (thick - V_l - V_s + e.V_ex) * rth;
+#else
   const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
   e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
   e.psi_s = V_s / thick;
   e.psi_l = (V_l - e.V_ex) / thick;
   e.psi_g = (thick - V_l - V_s + e.V_ex) / thick;
+#endif
   if (e.psi_l < 0.0) e.psi_l = 0.0;
   if (e.psi_g < 0.0) e.psi_g = 0.0;
   return e;
@@ -628,7 +665,11 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       } else {
         ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(r.minp, r.perm_bot);
       }
+#if SAMSIM_FAST_DIV
+      ray = ray * (1.0 / (kappa_l * mu));
+#else
       ray = ray / (kappa_l * mu);
+#endif
       ray = dmax(ray, 0.0);
       LAY(SAMSIM_A_RAY, k) = ray;
     }
@@ -726,11 +767,12 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
       m_n = LAY(SAMSIM_A_M, k + 1); th_n = LAY(SAMSIM_A_THICK, k + 1); T_n = LAY(SAMSIM_A_T, k + 1);
       H_n = LAY(SAMSIM_A_H_ABS, k + 1); S_n = LAY(SAMSIM_A_S_ABS, k + 1);
     }
-    const double S_bu_in = per_mass(S_abs, m);
+    double S_bu_in, H_in;
+    per_mass(S_abs, H_abs_in, m, S_bu_in, H_in);
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
     // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
     const double S_br = S_br_clamped(x.salt, T, S_bu_in);
-    const Expelled ex = expulsion(phi_from_T(x.salt, H_abs_in / m, S_bu_in, S_br), thick, m);
+    const Expelled ex = expulsion(phi_from_T(x.salt, H_in, S_bu_in, S_br), thick, m);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g;
     double flm_next;
@@ -1073,7 +1115,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   // default bench: loads at use 82.3 ms per launch, one layer ahead 76.0, two ahead at 3 waves/SIMD 73.8 (two ahead at
   // 4 waves/SIMD spills inside the loop: 93).
   struct Ld { double T, S_abs, m, H_abs, thick, ray; };
-  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray; };
+  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAY(SAMSIM_A_T, j);
@@ -1087,7 +1129,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   auto finish = [&](const Ld &l) -> Raw {
     Raw r;
     r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.thick = l.thick; r.ray = l.ray;
-    r.S_bu = per_mass(r.S_abs, r.m);
+    per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
   };
@@ -1109,7 +1151,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
     double H_abs = raw.H_abs;
-    const Expelled ex = expulsion(phi_from_T(s, H_abs / raw.m, raw.S_bu, raw.S_br), thick, raw.m);
+    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
@@ -1165,7 +1207,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       const double ray = raw.ray;
       if (ray > ray_crit && S_br > raw_n.S_br) {
         const double psi_s = ex.psi_s;
-        if (psi_s > 0.001 && S_abs / m > 0.1) {
+        if (psi_s > 0.001 && S_bu > 0.1) {  // S_bu = S_abs/m of this layer, formed above (j < N_active: nothing changed since)
           const double psi_l = ex.psi_l;
           double flux = x_grav * (ray - ray_crit) * dt * thick;
           flux = dmin(flux, psi_l * rho_l * thick);
