@@ -66,11 +66,11 @@ CONTAINS
     INTEGER :: Nlayer, N_top, N_bottom, ios, k_bgc
     INTEGER :: boundflux_flag, atmoflux_flag, albedo_flag, grav_flag, flush_flag, flood_flag, grav_heat_flag, &
                flush_heat_flag, harmonic_flag, salt_flag, turb_flag, bottom_flag, precip_flag, freeboard_snow_flag, &
-               snow_flush_flag, bgc_flag
+               snow_flush_flag, bgc_flag, prescribe_flag
     REAL(wp) :: dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush
     NAMELIST /samsim_flags/ Nlayer, N_top, N_bottom, boundflux_flag, atmoflux_flag, albedo_flag, grav_flag, flush_flag, &
          flood_flag, grav_heat_flag, flush_heat_flag, harmonic_flag, salt_flag, turb_flag, bottom_flag, precip_flag, &
-         freeboard_snow_flag, snow_flush_flag, bgc_flag, dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush, &
+         freeboard_snow_flag, snow_flush_flag, bgc_flag, prescribe_flag, dt, thick_0, time_out, time_total, T_bottom, S_bu_bottom, k_snow_flush, &
          fl_q_bottom, T_top, T2m, tank_depth
 
     CALL default_flags()
@@ -147,6 +147,7 @@ CONTAINS
        boundflux_flag = cfg%boundflux_flag; atmoflux_flag = cfg%atmoflux_flag; albedo_flag = cfg%albedo_flag
        grav_flag = cfg%grav_flag; flush_flag = cfg%flush_flag; flood_flag = cfg%flood_flag
        grav_heat_flag = cfg%grav_heat_flag; flush_heat_flag = cfg%flush_heat_flag; harmonic_flag = cfg%harmonic_flag
+       prescribe_flag = cfg%prescribe_flag
        salt_flag = cfg%salt_flag; turb_flag = cfg%turb_flag; bottom_flag = cfg%bottom_flag; precip_flag = cfg%precip_flag
        freeboard_snow_flag = cfg%freeboard_snow_flag; snow_flush_flag = cfg%snow_flush_flag; bgc_flag = cfg%bgc_flag
        dt = cfg%dt; thick_0 = cfg%thick_0; time_out = cfg%time_out; time_total = cfg%time_total
@@ -161,6 +162,7 @@ CONTAINS
        cfg%boundflux_flag = boundflux_flag; cfg%atmoflux_flag = atmoflux_flag; cfg%albedo_flag = albedo_flag
        cfg%grav_flag = grav_flag; cfg%flush_flag = flush_flag; cfg%flood_flag = flood_flag
        cfg%grav_heat_flag = grav_heat_flag; cfg%flush_heat_flag = flush_heat_flag; cfg%harmonic_flag = harmonic_flag
+       cfg%prescribe_flag = prescribe_flag
        cfg%salt_flag = salt_flag; cfg%turb_flag = turb_flag; cfg%bottom_flag = bottom_flag; cfg%precip_flag = precip_flag
        cfg%freeboard_snow_flag = freeboard_snow_flag; cfg%snow_flush_flag = snow_flush_flag; cfg%bgc_flag = bgc_flag
        cfg%dt = dt; cfg%thick_0 = thick_0; cfg%time_out = time_out; cfg%time_total = time_total

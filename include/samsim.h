@@ -41,13 +41,13 @@ typedef struct samsim_config {
   int32_t nlayer, n_top, n_middle, n_bottom;          /* mo_data.f90:62-65                           */
   int32_t atmoflux_flag;        /* 1 Notz climatology, 2 forcing tables, 3 fixed fl_sw / fl_rest     */
   int32_t grav_flag;            /* 1 none, 2 Rayleigh-number gravity drainage, 3 simple              */
-  int32_t prescribe_flag;       /* 1 (2 not supported)                                               */
+  int32_t prescribe_flag;       /* 1 none, 2 prescribed salinity profile (mo_grotz.f90:482-497)      */
   int32_t grav_heat_flag;       /* 1, 2                                                              */
   int32_t flush_heat_flag;      /* 1, 2                                                              */
   int32_t turb_flag;            /* 1, 2                                                              */
   int32_t salt_flag;            /* 1 sea salt, 2 NaCl                                                */
   int32_t boundflux_flag;       /* 1 cooling plate, 2 radiative balance, 3 lab air temperature T2m   */
-  int32_t flush_flag;           /* 1 none, 4 melt water removed, 5 flush3 (6 not supported)          */
+  int32_t flush_flag;           /* 1 none, 4 melt water removed, 5 flush3, 6 flush4                  */
   int32_t flood_flag;           /* 1 none, 2 flood, 3 flood_simple                                   */
   int32_t bottom_flag;          /* 1, 2                                                              */
   int32_t debug_flag;           /* 1 (ignored)                                                       */

@@ -21,6 +21,7 @@
 !!   SAMSIM_REF_BGC        0 -> sets bgc_flag=1 (tracers off; T/phi/S are unaffected, SURVEY.md 2 row 9)
 !!   SAMSIM_REF_TRACE_FROM / SAMSIM_REF_TRACE_TO   step window (inclusive) of per-step trace records
 !!   SAMSIM_REF_QUIET      1 -> no dump at all (timing runs)
+!!   SAMSIM_REF_FLUSH / _GRAV / _FLOOD / _PRESCRIBE   override flush_flag, grav_flag, flood_flag, prescribe_flag after init
 MODULE mo_output
 
   USE mo_parameters, ONLY: wp
@@ -185,7 +186,7 @@ CONTAINS
 
   SUBROUTINE output_begin(Nlayer,debug_flag,format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                           &format_melt)
-    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag, i_time_out
+    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag, i_time_out, flush_flag, grav_flag, flood_flag, prescribe_flag
     INTEGER,         INTENT(in)  :: Nlayer,debug_flag
     CHARACTER*12000, INTENT(out) :: format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                                     &format_melt
@@ -202,6 +203,15 @@ CONTAINS
     IF (found .AND. v > 0) i_time_out = v
     CALL env_int('SAMSIM_REF_BGC', v, found)
     IF (found .AND. v == 0) bgc_flag = 1
+    ! flag variants the reference's init holds as commented-out lines (mo_init.f90:1068-1071, 1386-1390)
+    CALL env_int('SAMSIM_REF_FLUSH', v, found)
+    IF (found) flush_flag = v
+    CALL env_int('SAMSIM_REF_GRAV', v, found)
+    IF (found) grav_flag = v
+    CALL env_int('SAMSIM_REF_FLOOD', v, found)
+    IF (found) flood_flag = v
+    CALL env_int('SAMSIM_REF_PRESCRIBE', v, found)
+    IF (found) prescribe_flag = v
     CALL env_int('SAMSIM_REF_TRACE_FROM', v, found)
     IF (found) trace_from = v
     CALL env_int('SAMSIM_REF_TRACE_TO', v, found)

@@ -33,6 +33,7 @@ static const double rho_s = 920.0, rho_l = 1028.0, latent_heat = 333500.0, zeroK
 static const double psi_s_min = 0.05, neg_free = -0.05;
 static const double x_grav = 0.000584, ray_crit = 4.89;
 static const double para_flush_horiz = 1.0;
+static const double para_flush_gamma = 0.9;                 /* mo_parameters.f90:81 */
 static const double psi_s_top_min = 0.40, ratio_flood = 1.50, ref_salinity = 34.0;
 static const double rho_snow = 330.0, gas_snow_ice2 = 0.20;
 static const double emissivity_ice = 0.95, emissivity_snow = 1.00, penetr = 0.30, extinc = 2.00;
@@ -1461,6 +1462,53 @@ static void output_point(column *c) {
   }
 }
 
+/* SUM(thick(a:b)) as the reference forms it: in ascending index order */
+static double thick_sum(const column *c, int a, int b) {
+  double s = 0.0;
+  for (int k = a; k <= b; k++) s += c->thick[k];
+  return s;
+}
+
+/* prescribe_flag 2, mo_grotz.f90:482-497: linear from S_bu_bottom to 4 over the lowest 0.15 m, from 4 to 0 above it.
+ * Layers the two loops do not reach keep the S_bu of the first sweep (layer 1 of ice thinner than 0.15 m). */
+static void prescribe_salinity(column *c) {
+  int N = c->N, Na = c->N_active, k = Na;
+  double Sb = c->S_bu_bottom;
+  while (k > 1 && thick_sum(c, k, Na) < 0.15) {
+    c->S_bu[k] = Sb - thick_sum(c, k, Na) / 0.15 * (Sb - 4.0);
+    k = k - 1;
+  }
+  while (k > 1 && thick_sum(c, k, Na) >= 0.15) {
+    c->S_bu[k] = 4.0 - 4.0 * (thick_sum(c, k, Na) - 0.15) / (thick_sum(c, 1, Na) - 0.15);
+    k = k - 1;
+    c->S_bu[1] = 0.0;
+  }
+  c->S_bu[Na] = Sb;
+  for (k = 1; k <= N; k++) c->S_abs[k] = c->S_bu[k] * c->m[k];
+}
+
+/* flush4, mo_flush.f90:253-296 (flush_flag 6): the melt water leaves the top layer with its brine salinity; every layer
+ * that is more liquid than the one above it loses the fraction 1 - para_flush_gamma of its salt, down to the first one
+ * that is not.  The reference's loop has no upper bound on k (it would read psi_l(Nlayer+1) on a column whose liquid
+ * fraction rises all the way down); here it ends at Nlayer. */
+static void flush4(column *c) {
+  int N = c->N, k;
+  double S_bu1 = c->S_abs[1] / c->m[1], mn;
+  c->H_abs[1] = c->H_abs[1] - c->melt_thick * rho_l * c_l * c->T[1];
+  c->S_abs[1] = c->S_abs[1] - c->melt_thick * rho_l * S_BR2(c->T[1], S_bu1);
+  c->thick[1] = c->thick[1] - c->melt_thick;
+  c->m[1] = c->m[1] - c->melt_thick * rho_l;
+  c->melt_thick = 0.0;
+  k = 2;
+  while (k <= N && c->psi_l[k] > c->psi_l[k - 1]) {
+    c->S_abs[k] = para_flush_gamma * c->S_abs[k];
+    k = k + 1;
+  }
+  c->S_abs[1] = (c->S_abs[1] > 0.0) ? c->S_abs[1] : 0.0;
+  mn = c->S_abs[1]; for (k = 1; k <= N; k++) if (c->S_abs[k] < mn) mn = c->S_abs[k];
+  if (mn < 0.0) STOP(9876, 0);
+}
+
 /* rest of the loop body: mo_grotz.f90:405-819 */
 static void step_part_b(column *c) {
   const samsim_config *g = c->cfg;
@@ -1497,6 +1545,9 @@ static void step_part_b(column *c) {
   /* gravity drainage :463-477 */
   if (g->grav_flag == 2 && Na > 1) { fl_grav_drain(c); CHECK(); }
   else if (g->grav_flag == 3 && Na > 1) fl_grav_drain_simple(c);
+
+  /* prescribed salinity profile :482-497 */
+  if (g->prescribe_flag == 2) prescribe_salinity(c);
 
   /* testcase specifics :503-565 */
   if (g->testcase == 1) sub_test1(c->time, &c->T_top);
@@ -1594,6 +1645,8 @@ static void step_part_b(column *c) {
           c->freeboard = freeboard_now(c);
           flush3(c); CHECK();
         }
+      } else if (g->flush_flag == 6) {                                                 /* :729-733 */
+        if (c->melt_thick > 0.000000000001 && Na > 2 && c->thick_snow < g->thick_0) { flush4(c); CHECK(); }
       }
     }
     for (k = 1; k <= N; k++) { c->flush_v[k] = c->flush_v[k] + fv_old[k]; c->flush_h[k] = c->flush_h[k] + fh_old[k]; }

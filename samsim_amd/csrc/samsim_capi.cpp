@@ -82,9 +82,9 @@ int validate(const samsim_config &c) {
   if (!in(c.boundflux_flag, {1, 2, 3}) || (c.boundflux_flag == 3 && c.lab_snow_flag != 0)) return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.atmoflux_flag, {1, 2, 3})) return SAMSIM_ERR_UNSUPPORTED;
   if (c.tank_flag == 2 && !(c.m_total > 0.0)) return SAMSIM_ERR_ARG;
-  if (!in(c.grav_flag, {1, 2, 3}) || c.prescribe_flag != 1 || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
+  if (!in(c.grav_flag, {1, 2, 3}) || !in(c.prescribe_flag, {1, 2}) || !in(c.grav_heat_flag, {1, 2}) || !in(c.flush_heat_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;
-  if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 4, 5}) || !in(c.flood_flag, {1, 2, 3}))
+  if (!in(c.turb_flag, {1, 2}) || !in(c.salt_flag, {1, 2}) || !in(c.flush_flag, {1, 4, 5, 6}) || !in(c.flood_flag, {1, 2, 3}))
     return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.bottom_flag, {1, 2}) || !in(c.precip_flag, {0, 1}) || !in(c.harmonic_flag, {1, 2}) || !in(c.tank_flag, {1, 2}))
     return SAMSIM_ERR_UNSUPPORTED;

@@ -40,7 +40,7 @@ constexpr double kappa_l = k_l / rho_l / c_l;
 constexpr double sigma = 5.6704 * (double)1e-8f;
 constexpr double psi_s_min = 0.05, neg_free = -0.05;
 constexpr double x_grav = 0.000584, ray_crit = 4.89;
-constexpr double para_flush_horiz = 1.0;
+constexpr double para_flush_horiz = 1.0, para_flush_gamma = 0.9;
 constexpr double psi_s_top_min = 0.40, ratio_flood = 1.50, ref_salinity = 34.0;
 constexpr double rho_snow = 330.0, gas_snow_ice2 = 0.20;
 constexpr double emissivity_ice = 0.95, emissivity_snow = 1.00, penetr = 0.30, extinc = 2.00;
@@ -743,6 +743,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   if (S_abs < 0.0) { S_abs = 0.0; LAY(SAMSIM_A_S_ABS, 1) = S_abs; }
   double S_bu, H;
   per_mass(S_abs, H_abs, m, S_bu, H);
+  if (K::general && CFG(prescribe_flag) == 2) LAY(SAMSIM_A_S_BU, 1) = S_abs / m;  // read back by prescribe_salinity
   const double T_test = (Na > 1) ? LAY(SAMSIM_A_T, 2) : g.T_bottom;
   double T, phi = 0.0;
   const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
@@ -1973,6 +1974,66 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
   (void)time;
 }
 
+// prescribe_flag 2, mo_grotz.f90:482-497: bulk salinity linear from S_bu_bottom to 4 over the lowest 0.15 m and from 4 to 0
+// above it.  The SUMs start afresh for every layer, in ascending order like the reference's; of S_bu only layer 1 is written (the up
+// sweep refreshes the others from S_abs before anything reads them).  Layer 1 of ice thinner than 0.15 m keeps the S_bu of the first sweep.
+template <class K>
+__device__ RARE void prescribe_salinity(Col &c, const Ctx &x) {
+  const int N = c.N, Na = c.Na;
+  const double Sb = x.S_bu_bottom;
+  auto thick_sum = [&](int a) { double t = 0.0; for (int j = a; j <= Na; ++j) t += LAY(SAMSIM_A_THICK, j); return t; };
+  const double total = thick_sum(1);
+  double S_bu1 = LAY(SAMSIM_A_S_BU, 1);
+  int k = Na;
+  while (k > 1) {
+    const double t = thick_sum(k);
+    if (!(t < 0.15)) break;
+    LAY(SAMSIM_A_S_ABS, k) = (Sb - t / 0.15 * (Sb - 4.0)) * LAY(SAMSIM_A_M, k);
+    k = k - 1;
+  }
+  while (k > 1) {
+    const double t = thick_sum(k);
+    if (!(t >= 0.15)) break;
+    LAY(SAMSIM_A_S_ABS, k) = (4.0 - 4.0 * (t - 0.15) / (total - 0.15)) * LAY(SAMSIM_A_M, k);
+    k = k - 1;
+    S_bu1 = 0.0;
+  }
+  // both loops ending above layer 1 takes SUMs that shrink as layers are added; the reference would then fall back on the
+  // S_bu array of the first sweep, which is not kept here
+  if (k > 1) STOPC(9001, k);
+  if (Na > 1) LAY(SAMSIM_A_S_ABS, Na) = Sb * LAY(SAMSIM_A_M, Na);
+  else S_bu1 = Sb;
+  LAY(SAMSIM_A_S_ABS, 1) = S_bu1 * LAY(SAMSIM_A_M, 1);
+  LAY(SAMSIM_A_S_BU, 1) = S_bu1;  // read by the thin-snow coupling of sub_heat_fluxes (mo_heat_fluxes.f90:293)
+  for (int j = Na + 1; j <= N; ++j) LAY(SAMSIM_A_S_ABS, j) = 0.0;
+}
+
+// flush4, mo_flush.f90:253-296 (flush_flag 6): the melt water leaves the top layer with its brine salinity; every layer more
+// liquid than the one above loses the fraction 1 - para_flush_gamma of its salt, down to the first one that is not
+// (layers below N_active hold no salt, so the walk may end there).
+template <class K>
+__device__ RARE void flush4(Col &c, const Ctx &x) {
+  const int Na = c.Na;
+  const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1), melt = c.melt_thick;
+  double S1 = LAY(SAMSIM_A_S_ABS, 1);
+  LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - melt * rho_l * c_l * T1;
+  S1 = S1 - melt * rho_l * S_br_clamped(x.salt, T1, S1 / m1);
+  LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - melt;
+  LAY(SAMSIM_A_M, 1) = m1 - melt * rho_l;
+  c.melt_thick = 0.0;
+  double above = LAY(SAMSIM_A_PSI_L, 1);
+  for (int k = 2; k <= Na; ++k) {
+    const double here = LAY(SAMSIM_A_PSI_L, k);
+    if (!(here > above)) break;
+    LAY(SAMSIM_A_S_ABS, k) = para_flush_gamma * LAY(SAMSIM_A_S_ABS, k);
+    above = here;
+  }
+  LAY(SAMSIM_A_S_ABS, 1) = dmax(S1, 0.0);
+  double mn = 0.0;
+  for (int k = 2; k <= Na; ++k) mn = dmin(mn, LAY(SAMSIM_A_S_ABS, k));
+  if (mn < 0.0) STOPC(9876, 0);
+}
+
 // testcase specifics that only touch scalars, mo_grotz.f90:503-565
 template <class K>
 __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g, double time) {
@@ -2070,6 +2131,7 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     } else if (do_beer) {
       sweep_beer<K>(c, beer0);
     }
+    if (K::general && CFG(prescribe_flag) == 2) prescribe_salinity<K>(c, x);  // mo_grotz.f90:482-497
     if (K::general && CFG(testcase) == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
       for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
     }
@@ -2127,7 +2189,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool flood_possible = (CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
-                     !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC;
+                     !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
+                     !(K::general && CFG(prescribe_flag) == 2);
 
   if (fused) {
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
@@ -2235,7 +2298,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 
   // flushing, mo_grotz.f90:670-737
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
-  const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && CFG(flush_flag) == 4)) && Na > 2 &&
+  const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
                                c.melt_thick + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !c.psi_full) STOPC(9001, 0);
   if (flush_possible && !fb_valid) c.freeboard = func_freeboard<K>(c, x);
@@ -2260,6 +2323,12 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
         LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (c.melt_thick * rho_l) / m1);
         LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - c.melt_thick;
         LAY(SAMSIM_A_M, 1) = m1 - c.melt_thick * rho_l;
+      } else if (K::general && CFG(flush_flag) == 6) {  // :729-733
+        if (c.thick_snow < g.thick_0) {
+          flush4<K>(c, x);
+          c.flags |= COLF_DIRTY;
+          if (c.status) return;
+        }
       } else {
         if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
         flush3<K>(c, x);

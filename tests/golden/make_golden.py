@@ -27,6 +27,9 @@ Fixtures are DATA only -- inputs and expected outputs:
                             reference's fl_grav_drain_simple reads an uninitialised local, so its own trajectory depends on
                             stack history), layers at selected ones, and teacher-forcing pairs through the first
                             two years (growth, melt with flush_flag 4, refreeze)
+  tc5_prescribe_ref.npz /   testcase 5 with the flag sets its init keeps commented out: prescribed salinity profile (flush_flag 4,
+  tc5_flush6_ref.npz /      grav_flag 1, flood_flag 1, prescribe_flag 2) and flush4 (flush_flag 6); testcase 7 with the prescribe set,
+  tc7_prescribe_ref.npz     first 200 output points (open water, then ice growing through the 0.15 m the profile's lower branch spans)
 """
 import os
 import subprocess
@@ -207,6 +210,26 @@ def main():
         d["tf_" + k] = v
     d["tf_index"] = np.array(pairs)
     np.savez_compressed(os.path.join(OUT, "tc7_ref_fullprec.npz"), **d)
+
+    # --- flag variants the reference's init keeps as commented-out lines (mo_init.f90:1068-1071, 1386-1390): the
+    # "prescribe" set (flush_flag 4, grav_flag 1, flood_flag 1, prescribe_flag 2) on testcases 5 and 7, and flush_flag 6
+    # (flush4) on testcase 5; the flags are overridden after init by oracle/ref_hook/ref_output_hook.f90
+    variants = {"prescribe": {"SAMSIM_REF_FLUSH": "4", "SAMSIM_REF_GRAV": "1", "SAMSIM_REF_FLOOD": "1", "SAMSIM_REF_PRESCRIBE": "2"},
+                "flush6": {"SAMSIM_REF_FLUSH": "6"}}
+    for name, env in variants.items():
+        recs = cached(5, f"tc5_{name}.bin", env)
+        d = pack(recs[5::6])
+        d["index"] = np.arange(len(recs))[5::6]
+        for k, v in pack(recs, with_layers=False).items():
+            d["all_" + k] = v
+        np.savez_compressed(os.path.join(OUT, f"tc5_{name}_ref.npz"), **d)
+    recs = cached(7, "tc7_prescribe.bin", dict(variants["prescribe"], SAMSIM_REF_MAXSTEPS="900000"))[:200]
+    sel = [0, 131, 133, 136, 140, 146, 155, 170, 199]
+    d = pack([recs[i] for i in sel])
+    d["index"] = np.array(sel)
+    for k, v in pack(recs, with_layers=False).items():
+        d["all_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "tc7_prescribe_ref.npz"), **d)
 
     # --- spun-up step-boundary checkpoints from the oracle
     cfg, st = tcs.testcase1(1)

@@ -2,6 +2,7 @@
 files it writes for testcase 1 must reproduce the reference's committed known answers
 (reference_output/Reference_testcase1_with_Version_2) digit for digit, up to values sitting on a rounding tie."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -98,6 +99,20 @@ def test_fortran_host_testcases_3_and_5(tmp_path):
         if i < T.shape[0]:
             na = int(ref["all_N_active"][i])
             assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc5 output {i}"
+    # the "prescribe" flag set init(5) keeps commented out (mo_init.f90:1068-1071), through the namelist
+    dp = tmp_path / "tc5p"
+    dp.mkdir()
+    run_host(dp, "&samsim_run testcase=5, ncol=8, max_steps=40000 /\n"
+                 "&samsim_flags flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2 /\n")
+    ref = golden("tc5_prescribe_ref.npz")
+    T, S = load(dp, "T"), load(dp, "S_bu")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    for i, j in rows.items():
+        if i < T.shape[0]:
+            na = int(ref["all_N_active"][i])
+            assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc5 prescribe output {i}"
+            assert np.abs(S[i, :na] - ref["a_S_bu"][j, :na]).max() <= 1.5e-3, f"tc5 prescribe output {i}"
+    assert re.search(r"prescribe_flag\s*=?\s*2", (dp / "output" / "dat_settings.dat").read_text())
 
 
 @pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")

@@ -216,7 +216,7 @@ def test_failed_columns_are_frozen_and_reported():
 
 
 def test_unsupported_flags_are_rejected():
-    for flag, value in (("prescribe_flag", 2), ("flush_flag", 6), ("lab_snow_flag", 1)):
+    for flag, value in (("prescribe_flag", 3), ("flush_flag", 3), ("lab_snow_flag", 1)):
         cfg, _ = tcs.testcase2(1) if flag == "lab_snow_flag" else tcs.testcase1(1)
         setattr(cfg, flag, value)
         with pytest.raises(samsim_amd.SamsimError) as e:

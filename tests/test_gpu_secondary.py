@@ -226,3 +226,45 @@ def test_grid_of_columns_on_four_forcing_sites():
     sg, so = _check(g, o, "four sites, +30000")
     T2m = so.sc("T2m")
     assert len({round(float(T2m[site == k].mean()), 3) for k in range(4)}) == 4      # the four sites really differ
+
+
+VARIANTS = {"prescribe": dict(flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2), "flush6": dict(flush_flag=6)}
+
+
+@pytest.mark.parametrize("tc,variant,nout", [(5, "prescribe", 240), (5, "flush6", 240), (7, "prescribe", 150)])
+def test_flag_variants_against_reference_records(tc, variant, nout):
+    """the flag sets init(5) / init(7) keep commented out (mo_init.f90:1068-1071, 1386-1390): prescribed salinity profile
+    (prescribe_flag 2 with flush_flag 4, grav_flag 1, flood_flag 1) and flush4 (flush_flag 6).  Free run of one column against
+    the reference's own output records (fixture) -- testcase 5 to the end of the run (melt of the 1 m slab), testcase 7 from
+    open water through freeze-up and the 0.15 m lower branch of the profile -- then against the oracle's state."""
+    cfg, st = getattr(tcs, f"testcase{tc}")(1)
+    for k, v in VARIANTS[variant].items():
+        setattr(cfg, k, v)
+    g = samsim_amd.hip_solver(cfg, 1)
+    o = oracle_solver(cfg, 1)
+    for s in (g, o):
+        if tc == 7:
+            s.set_forcing(*sheba_forcing())
+        s.set_state(st)
+        s.set_clock()
+    g.set_output_window(0, 1)
+    ref = golden(f"tc{tc}_{variant}_ref.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    rtol = 1e-6
+    for i in range(nout):
+        out = g.run_to_output()
+        assert out.step == ref["all_step"][i] and out.n_active[0] == ref["all_N_active"][i], f"output {i}"
+        for n, floor in (("m_snow", 1e-5), ("thick_snow", 1e-7), ("T_snow", 1e-2), ("T_top", 1e-2), ("freeboard", 1e-7),
+                         ("thickness", 1e-7), ("bulk_salin", 1e-5)):
+            assert rel_err(out.sc(n)[0], ref["all_s_" + n][i], floor) <= rtol, f"output {i}: {n} vs reference"
+        if i in rows:
+            na, j = int(out.n_active[0]), rows[i]
+            for n in ["T", "psi_s", "psi_l", "S_bu", "thick"]:
+                assert rel_err(out.arr(n)[:na, 0], ref["a_" + n][j, :na], 1e-7) <= rtol, f"output {i}: {n} vs reference"
+    assert not g.get_status()[0].any()
+    o.step(g.get_clock().step)
+    _check(g, o, f"tc{tc} {variant} after {nout} outputs", rtol)
+    if variant == "flush6":
+        assert ref["a_S_bu"][-1, 1] < 1e-6           # flush4 has rinsed the upper layers
+    if tc == 7:
+        assert ref["all_N_active"][nout - 1] > 15     # past the 0.15 m the lower branch of the profile spans

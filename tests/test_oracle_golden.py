@@ -200,6 +200,30 @@ def test_tc5_fixed_flux_flushing_bitwise():
     assert not o.get_status()[0].any()
 
 
+VARIANTS = {"prescribe": dict(flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2), "flush6": dict(flush_flag=6)}
+
+
+@pytest.mark.parametrize("tc,variant,nout", [(5, "prescribe", 240), (5, "flush6", 240), (7, "prescribe", 200)])
+def test_flag_variants_bitwise(tc, variant, nout):
+    """the flag sets init(5) and init(7) keep as commented-out lines (mo_init.f90:1068-1071, 1386-1390), run by the reference
+    with the flags overridden after init: the prescribed salinity profile (prescribe_flag 2, mo_grotz.f90:482-497; testcase 7
+    grows from open water through the profile's 0.15 m lower branch) and flush4 (flush_flag 6, mo_flush.f90:253-296)"""
+    cfg, st = getattr(tcs, f"testcase{tc}")(1)
+    for k, v in VARIANTS[variant].items():
+        setattr(cfg, k, v)
+    o = oracle_solver(cfg, 1)
+    if tc == 7:
+        o.set_forcing(*sheba_forcing())
+    o.set_state(st)
+    o.set_clock()
+    ref = golden(f"tc{tc}_{variant}_ref.npz")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    assert len(ref["all_step"]) == nout
+    for i in range(nout):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"tc{tc} {variant} output {i}")
+    assert not o.get_status()[0].any()
+
+
 @pytest.mark.parametrize("tc,nout", [(2, 120), (6, 156), (9, 72)])
 def test_tank_experiments_bitwise(tc, nout):
     """testcases 2, 6, 9 (boundflux_flag 3: air temperature over a tank; tank_flag 2: S_bu_bottom from the salt budget;
