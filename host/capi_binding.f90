@@ -143,6 +143,18 @@ MODULE mo_samsim_capi
        REAL(c_double), INTENT(in) :: bgc_abs(*)           ! (ncols, nlayer, n_bgc), column fastest
        INTEGER(c_int64_t), VALUE :: col0, ncols
      END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_tracer_bottom(h, bgc_bottom, col0, ncols) BIND(C, name='samsim_set_tracer_bottom')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       REAL(c_double), INTENT(in) :: bgc_bottom(*)        ! (ncols, n_bgc), column fastest
+       INTEGER(c_int64_t), VALUE :: col0, ncols
+     END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_get_tracer_state(h, bgc_abs, bgc_bottom, col0, ncols) BIND(C, name='samsim_get_tracer_state')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       REAL(c_double), INTENT(out) :: bgc_abs(*), bgc_bottom(*)
+       INTEGER(c_int64_t), VALUE :: col0, ncols
+     END FUNCTION
      INTEGER(c_int) FUNCTION samsim_get_tracer_output(h, bgc_abs, bgc_bottom) BIND(C, name='samsim_get_tracer_output')
        IMPORT
        TYPE(c_ptr), VALUE :: h

@@ -484,15 +484,17 @@ CONTAINS
     INTEGER(c_int64_t), PARAMETER :: chunk = 65536
     TYPE(samsim_state_soa) :: st
     TYPE(samsim_clock)     :: clk
-    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :)
+    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :), bbgc(:, :, :), bbot(:, :)
     INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
-    INTEGER(c_int64_t) :: c0, n
+    INTEGER(c_int64_t) :: c0, n, nb
     INTEGER :: u
+    nb = 0
+    IF (cfg%bgc_flag == 2) nb = N_bgc
     CALL samsim_check(samsim_get_clock(h, clk), 'samsim_get_clock')
     OPEN(NEWUNIT=u, file=TRIM(path), STATUS='replace', ACCESS='stream', FORM='unformatted')
     WRITE(u) restart_magic, ncol, INT(cfg%nlayer, c_int64_t), INT(SAMSIM_NARR, c_int64_t), INT(SAMSIM_NSCAL, c_int64_t), &
          INT(cfg%testcase, c_int64_t), clk%time, clk%step, INT(clk%n_time_out, c_int64_t), INT(clk%time_counter, c_int64_t), &
-         clk%n_outputs, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t
+         clk%n_outputs, nb, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t
     c0 = 0
     DO WHILE (c0 < ncol)
        n = MIN(chunk, ncol - c0)
@@ -505,6 +507,13 @@ CONTAINS
        WRITE(u) bscal
        WRITE(u) bna
        DEALLOCATE(blay, bscal, bna)
+       IF (nb > 0) THEN                     ! tracer amounts and the concentration of the water below
+          ALLOCATE(bbgc(n, cfg%nlayer, nb), bbot(n, nb))
+          CALL samsim_check(samsim_get_tracer_state(h, bbgc, bbot, c0, n), 'samsim_get_tracer_state')
+          WRITE(u) bbgc
+          WRITE(u) bbot
+          DEALLOCATE(bbgc, bbot)
+       END IF
        c0 = c0 + n
     END DO
     CLOSE(u)
@@ -516,16 +525,22 @@ CONTAINS
     CHARACTER(len=*), INTENT(in) :: path
     TYPE(samsim_state_soa) :: st
     TYPE(samsim_clock)     :: clk
-    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :)
+    REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :), bbgc(:, :, :), bbot(:, :)
     INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
-    INTEGER(c_int64_t) :: hdr(6), tail(3), pad(5), c0, n, done
+    INTEGER(c_int64_t) :: hdr(6), tail(3), pad(5), c0, n, done, nb
     INTEGER :: u
+    nb = 0
+    IF (cfg%bgc_flag == 2) nb = N_bgc
     OPEN(NEWUNIT=u, file=TRIM(path), STATUS='old', ACCESS='stream', FORM='unformatted')
     READ(u) hdr, clk%time, clk%step, tail, pad
     IF (hdr(1) /= restart_magic .OR. hdr(2) /= ncol .OR. hdr(3) /= cfg%nlayer .OR. hdr(5) /= SAMSIM_NSCAL .OR. &
          (hdr(4) /= SAMSIM_NARR .AND. hdr(4) /= SAMSIM_NPROG)) THEN
        PRINT *, 'restart file does not fit this run (magic, ncol, Nlayer, narr, nscal):', hdr(1:5)
        STOP 5
+    END IF
+    IF (pad(1) /= nb) THEN
+       PRINT *, 'restart file holds', pad(1), 'tracers, this run', nb
+       STOP 6
     END IF
     clk%n_time_out = INT(tail(1), c_int32_t); clk%time_counter = INT(tail(2), c_int32_t); clk%n_outputs = tail(3)
     done = 0
@@ -539,6 +554,14 @@ CONTAINS
        st%lay = c_loc(blay); st%scal = c_loc(bscal); st%n_active = c_loc(bna)
        CALL samsim_check(samsim_set_state(h, st, c0), 'samsim_set_state')
        DEALLOCATE(blay, bscal, bna)
+       IF (nb > 0) THEN
+          ALLOCATE(bbgc(n, cfg%nlayer, nb), bbot(n, nb))
+          READ(u) bbgc
+          READ(u) bbot
+          CALL samsim_check(samsim_set_tracer_state(h, bbgc, c0, n), 'samsim_set_tracer_state')
+          CALL samsim_check(samsim_set_tracer_bottom(h, bbot, c0, n), 'samsim_set_tracer_bottom')
+          DEALLOCATE(bbgc, bbot)
+       END IF
        done = done + n
     END DO
     CLOSE(u)
@@ -596,10 +619,6 @@ CONTAINS
        ALLOCATE(obgc(1, cfg%nlayer, N_bgc), obot(1, N_bgc))
     END IF
     CALL samsim_check(samsim_set_state(h, st, 0_c_int64_t), 'samsim_set_state')
-    IF (cfg%bgc_flag == 2 .AND. (LEN_TRIM(restart_in) > 0 .OR. LEN_TRIM(restart_out) > 0)) THEN
-       PRINT *, 'restart files do not hold the tracers: run with &samsim_flags bgc_flag = 1 or without restart_in/restart_out'
-       STOP 6
-    END IF
     IF (LEN_TRIM(restart_in) > 0) CALL read_restart(h, restart_in)
     CALL samsim_check(samsim_set_output_window(h, INT(out_col - 1, c_int64_t), 1_c_int64_t), 'samsim_set_output_window')
     ALLOCATE(olay(1, cfg%nlayer, SAMSIM_NARR), oscal(1, SAMSIM_NSCAL), ona(1))

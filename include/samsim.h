@@ -189,6 +189,9 @@ int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *colu
 int samsim_set_tracers(samsim_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total);
 int samsim_set_tracer_state(samsim_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols);
 int samsim_get_tracer_state(samsim_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols);
+/* restart only: the per-column concentration of the water below, bgc_bottom[n_bgc][ncols], as samsim_get_tracer_state
+ * returned it (it evolves with the tank budget, mo_grotz.f90:575-577; samsim_set_tracers sets one value for all columns) */
+int samsim_set_tracer_bottom(samsim_handle *h, const double *bgc_bottom, int64_t col0, int64_t ncols);
 int samsim_get_tracer_output(samsim_handle *h, double *bgc_abs, double *bgc_bottom);
 
 /* Ensemble statistics (what replaces "one column per .dat row", mo_output.f90:129-144, when the

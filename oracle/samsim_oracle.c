@@ -1777,6 +1777,13 @@ int oracle_set_tracer_state(oracle_handle *h, const double *bgc_abs, int64_t col
   return SAMSIM_OK;
 }
 
+int oracle_set_tracer_bottom(oracle_handle *h, const double *bgc_bottom, int64_t col0, int64_t ncols) {
+  if (!h || !bgc_bottom || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  for (int64_t i = 0; i < ncols; i++)
+    for (int t = 0; t < h->n_bgc; t++) h->cols[col0 + i].bgc_bottom[t] = bgc_bottom[(size_t)t * ncols + i];
+  return SAMSIM_OK;
+}
+
 int oracle_get_tracer_state(oracle_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols) {
   if (!h || !bgc_abs || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
   int N = h->cfg.nlayer;

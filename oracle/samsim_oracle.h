@@ -46,6 +46,7 @@ int  oracle_get_status(oracle_handle *h, int32_t *status, int64_t *step, int32_t
 int  oracle_get_work(oracle_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
 int  oracle_set_tracers(oracle_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total);
 int  oracle_set_tracer_state(oracle_handle *h, const double *bgc_abs, int64_t col0, int64_t ncols);
+int  oracle_set_tracer_bottom(oracle_handle *h, const double *bgc_bottom, int64_t col0, int64_t ncols);
 int  oracle_get_tracer_state(oracle_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols);
 int  oracle_get_tracer_output(oracle_handle *h, double *bgc_abs, double *bgc_bottom);
 int  oracle_get_ensemble_stats(oracle_handle *h, int32_t nslots, const int32_t *slots, samsim_stat *out);

@@ -192,7 +192,7 @@ class Solver:
             "get_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
             "get_work": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
             "get_ensemble_stats": [vp, i32, C.POINTER(C.c_int32), C.POINTER(Stat)],
-            "set_tracers": [vp, i32, dp, dp], "set_tracer_state": [vp, dp, i64, i64],
+            "set_tracers": [vp, i32, dp, dp], "set_tracer_state": [vp, dp, i64, i64], "set_tracer_bottom": [vp, dp, i64, i64],
             "get_tracer_state": [vp, dp, dp, i64, i64], "get_tracer_output": [vp, dp, dp],
         }
         for n, a in sig.items():
@@ -309,6 +309,12 @@ class Solver:
         a = np.ascontiguousarray(bgc_abs, dtype=np.float64)
         assert a.shape[:2] == (self.n_bgc, self.nlayer)
         self._chk(self._f("set_tracer_state")(self._h, _dp(a), col0, a.shape[2]), "set_tracer_state")
+
+    def set_tracer_bottom(self, bgc_bottom, col0: int = 0):
+        """bgc_bottom[n_bgc][ncols]: per-column concentration below the ice, as get_tracer_state returned it (restart)"""
+        b = np.ascontiguousarray(bgc_bottom, dtype=np.float64)
+        assert b.shape[0] == self.n_bgc
+        self._chk(self._f("set_tracer_bottom")(self._h, _dp(b), col0, b.shape[1]), "set_tracer_bottom")
 
     def get_tracer_state(self, col0: int = 0, ncols: int | None = None):
         n = self.ncol - col0 if ncols is None else ncols

@@ -572,6 +572,17 @@ int samsim_set_tracer_state(samsim_handle *h, const double *bgc_abs, int64_t col
   return SAMSIM_OK;
 }
 
+int samsim_set_tracer_bottom(samsim_handle *h, const double *bgc_bottom, int64_t col0, int64_t ncols) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!bgc_bottom || h->n_bgc < 1 || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t nc = (size_t)h->ncol, w = (size_t)ncols;
+  HIPCHK(hipMemcpy2D(h->bgc_bot + col0, nc * sizeof(double), bgc_bottom, w * sizeof(double), w * sizeof(double), (size_t)h->n_bgc,
+                     hipMemcpyHostToDevice));
+  return SAMSIM_OK;
+}
+
 int samsim_get_tracer_state(samsim_handle *h, double *bgc_abs, double *bgc_bottom, int64_t col0, int64_t ncols) {
   int rc = use(h);
   if (rc) return rc;

@@ -101,6 +101,39 @@ def test_checkpoint_restart_continues_bitwise(tmp_path):
         assert np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-3)) <= 1e-9, n
 
 
+def test_checkpoint_with_tracers_continues_bitwise(tmp_path):
+    """testcase 6 as init ships it (tank_flag 2 + one tracer: the concentration of the water below is per-column state):
+    save -> new handle -> set_tracers -> load is bit-identical to the uninterrupted run, tracers included"""
+    ncol = 200
+    cfg, st = tcs.testcase6(ncol)
+    bottom, total, q = tcs.tracers(cfg, st)
+
+    def fresh():
+        g = samsim_amd.hip_solver(cfg, ncol)
+        g.set_tracers(bottom, total)
+        return g
+    a = fresh()
+    a.set_state(st)
+    a.set_tracer_state(q)
+    a.set_clock()
+    a.step(20000)
+    path = str(tmp_path / "bgc.chk")
+    checkpoint.save(a, path, chunk=128)
+    b = fresh()
+    assert checkpoint.load(b, path)["n_bgc"] == 1
+    a.step(5000)
+    b.step(5000)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa.n_active, sb.n_active) and sa.n_active.min() > 3
+    assert np.array_equal(sa.lay[:4], sb.lay[:4]) and np.array_equal(sa.scal, sb.scal)
+    (qa, ba), (qb, bb) = a.get_tracer_state(), b.get_tracer_state()
+    assert np.array_equal(qa, qb) and np.array_equal(ba, bb)
+    assert ba.min() > bottom[0]                               # the tank's water got richer in tracer
+    cfg0, _ = tcs.testcase6(ncol)
+    with pytest.raises(ValueError):
+        checkpoint.load(samsim_amd.hip_solver(cfg0, ncol), path)
+
+
 @pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")
 def test_fortran_host_restart_and_ensemble_file(tmp_path):
     """the Fortran host: run, write a restart file, continue from it in a second process; the rows printed after the restart
@@ -113,17 +146,21 @@ def test_fortran_host_restart_and_ensemble_file(tmp_path):
         r = subprocess.run([HOST], cwd=d, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return r.stdout
-    run(tmp_path / "full", "&samsim_run testcase=1, ncol=96, max_steps=12000 /\n&samsim_flags bgc_flag=1 /\n")
-    run(tmp_path / "part1", "&samsim_run testcase=1, ncol=96, max_steps=7300, restart_out='../tc1.chk' /\n&samsim_flags bgc_flag=1 /\n")
-    out = run(tmp_path / "part2", "&samsim_run testcase=1, ncol=96, max_steps=12000, restart_in='../tc1.chk' /\n&samsim_flags bgc_flag=1 /\n")
+    # init(1) as it ships: two passive tracers, which the restart file carries
+    run(tmp_path / "full", "&samsim_run testcase=1, ncol=96, max_steps=12000 /\n")
+    run(tmp_path / "part1", "&samsim_run testcase=1, ncol=96, max_steps=7300, restart_out='../tc1.chk' /\n")
+    out = run(tmp_path / "part2", "&samsim_run testcase=1, ncol=96, max_steps=12000, restart_in='../tc1.chk' /\n")
     assert "restarted from" in out
     hdr = checkpoint.read_header(str(tmp_path / "tc1.chk"))
-    assert (hdr["ncol"], hdr["nlayer"], hdr["step"], hdr["narr"], hdr["testcase"]) == (96, 90, 7300, 15, 1)
+    assert (hdr["ncol"], hdr["nlayer"], hdr["step"], hdr["narr"], hdr["testcase"], hdr["n_bgc"]) == (96, 90, 7300, 15, 1, 2)
     full = (tmp_path / "full" / "output" / "dat_T.dat").read_text().splitlines()
     p1 = (tmp_path / "part1" / "output" / "dat_T.dat").read_text().splitlines()
     p2 = (tmp_path / "part2" / "output" / "dat_T.dat").read_text().splitlines()
     assert len(full) == 4 and len(p1) == 3 and len(p2) == 1        # outputs at steps 1, 3602, 7203, 10804
     assert p1 == full[:3] and p2 == full[3:]
+    for name in ("dat_bgc01.bu.dat", "dat_bgc02.br.dat"):
+        f, q1, q2 = ((tmp_path / d / "output" / name).read_text().splitlines() for d in ("full", "part1", "part2"))
+        assert len(f) == 4 and q1 == f[:3] and q2 == f[3:], name
     ens = np.loadtxt(tmp_path / "full" / "output" / "dat_ensemble.dat")
     assert ens.shape == (4, 26) and (ens[:, 1] == 96).all()
     thick = np.loadtxt(tmp_path / "full" / "output" / "dat_vital_signs.dat")

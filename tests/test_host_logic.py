@@ -89,6 +89,41 @@ def test_checkpoint_file_roundtrip_and_bitwise_continuation(tmp_path):
         checkpoint.load(oracle_solver(cfg, ncol + 1), path)
 
 
+def test_checkpoint_with_tracers_continues_bitwise(tmp_path):
+    """a tank experiment with its tracer (init(6): bgc_flag 2, tank_flag 2, so that the concentration of the water below is
+    per-column state): save -> new handle -> set_tracers -> load continues bit for bit; a handle without tracers refuses"""
+    from samsim_amd import checkpoint
+    ncol = 3
+    cfg, st = tcs.testcase6(ncol)
+    bottom, total, q = tcs.tracers(cfg, st)
+
+    def fresh():
+        o = oracle_solver(cfg, ncol)
+        o.set_tracers(bottom, total)
+        return o
+    a = fresh()
+    a.set_state(st)
+    a.set_tracer_state(q)
+    a.set_clock()
+    a.step(20000)
+    assert a.get_state().n_active.min() > 3
+    path = str(tmp_path / "restart_bgc.chk")
+    checkpoint.save(a, path, chunk=2)
+    assert checkpoint.read_header(path)["n_bgc"] == 1
+    b = fresh()
+    checkpoint.load(b, path)
+    a.step(5000)
+    b.step(5000)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa.lay, sb.lay) and np.array_equal(sa.scal, sb.scal) and np.array_equal(sa.n_active, sb.n_active)
+    (qa, ba), (qb, bb) = a.get_tracer_state(), b.get_tracer_state()
+    assert np.array_equal(qa, qb) and np.array_equal(ba, bb)
+    assert ba.min() > bottom[0] and qa[0, 2].min() > 0.0        # the tank got richer, the ice holds tracer
+    cfg0, _ = tcs.testcase6(ncol)
+    with pytest.raises(ValueError):
+        checkpoint.load(oracle_solver(cfg0, ncol), path)
+
+
 def test_ensemble_statistics_of_the_checker():
     """samsim_get_ensemble_stats semantics (count / mean / min / max / population std over the columns without a STOP
     code) on the checker library against numpy"""
