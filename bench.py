@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--nlayer", type=int, default=80,
                     help="SHEBA geometry: 80 = 20+40+20 (the N_layers BASELINE.json's metric is quoted on) or 100 = 20+60+20 "
                          "(testcase 4 as shipped)")
+    ap.add_argument("--sites", type=int, default=1,
+                    help="forcing sets (samsim_set_forcing_sites): the tables replicated N times, column c on set c mod N")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,7 +147,10 @@ def main():
     ncol = args.ncol
     col0 = rank * ncol
     g = samsim_amd.hip_solver(cfg, ncol, device=local_rank)
-    if forcing is not None:
+    if forcing is not None and args.sites > 1:
+        g.set_forcing_sites(*[np.tile(a, (args.sites, 1)) for a in forcing], (np.arange(ncol) % args.sites).astype(np.int32),
+                            tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
+    elif forcing is not None:
         g.set_forcing(*forcing, tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
     upload_tiled(g, st, ncol, col0)
     g.set_clock(**clock)
@@ -203,7 +208,7 @@ def main():
             "data": "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; synthetic spun-up ensemble (fixture)"
                     if args.workload == "sheba" else "synthetic: replicated spun-up testcase-1 state",
             "config": {"workload": wname, "ncol_per_gpu": ncol, "nlayer": nlayer, "timesteps_per_step": args.substeps,
-                       "parallelism": f"columns sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"columns sharded over {world} GPU(s), no collective", "forcing_sites": args.sites},
             "layer_cell_updates_per_s": cells / wall_max,
             "failed_columns": int(fails),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -64,20 +64,23 @@ constexpr double Turb_B = 0.05;
   X(boundflux_flag) X(flush_flag) X(flood_flag) X(bottom_flag) X(precip_flag) X(harmonic_flag) X(tank_flag) X(albedo_flag) \
   X(lab_snow_flag) X(freeboard_snow_flag) X(snow_flush_flag) X(snow_precip_flag) X(testcase)
 struct KGeneric {
-  static constexpr bool fixed = false, general = true;
+  static constexpr bool fixed = false, general = true, sites = true;
 #define X(f) [[maybe_unused]] static constexpr int f = 0;
   SAMSIM_FLAG_LIST(X)
 #undef X
 };
 struct KSheba {  // init(4), mo_init.f90:1127-1207 on the defaults of :83-109
-  static constexpr bool fixed = true, general = false;
+  static constexpr bool fixed = true, general = false, sites = false;
   static constexpr int atmoflux_flag = 2, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 2, turb_flag = 2,
                        salt_flag = 1, boundflux_flag = 2, flush_flag = 5, flood_flag = 2, bottom_flag = 1, precip_flag = 1,
                        harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
                        snow_flush_flag = 1, snow_precip_flag = 1, testcase = 4;
 };
+struct KShebaSites : KSheba {  // the same on several forcing sets (samsim_set_forcing_sites): a grid of columns
+  static constexpr bool sites = true;
+};
 struct KPlate {  // init(1), mo_init.f90:865-945 (bgc off)
-  static constexpr bool fixed = true, general = false;
+  static constexpr bool fixed = true, general = false, sites = false;
   static constexpr int atmoflux_flag = 1, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 1, turb_flag = 1,
                        salt_flag = 2, boundflux_flag = 1, flush_flag = 1, flood_flag = 2, bottom_flag = 1, precip_flag = 0,
                        harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
@@ -2401,7 +2404,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.bgc = (gdouble *)bgc; x.bgc_bot = (gdouble *)bgc_bot; x.bfl = (gdouble *)bfl;
   x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
   x.n_bgc = K::general ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
-  x.soff = (K::general && p.nsites > 1) ? site[col] * p.flen : 0;
+  x.soff = (K::sites && p.nsites > 1) ? site[col] * p.flen : 0;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   x.S_bu_bottom = (K::general && (K::fixed ? K::tank_flag : p.cfg.tank_flag) == 2) ? scal[(size_t)SAMSIM_S_S_BU_BOTTOM * (size_t)p.ncol + (size_t)col] : p.cfg.S_bu_bottom;
@@ -2492,9 +2495,11 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
-  const bool tracers = g.bgc_flag == 2 || hp->nsites > 1;   // tracers and per-column forcing sets exist in the run-time-flag instantiation only
-  auto kernel = (!tracers && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
-                : (!tracers && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
+  // tracers exist in the run-time-flag instantiation only; several forcing sets there and in the SHEBA one
+  const bool tracers = g.bgc_flag == 2, sites = hp->nsites > 1;
+  auto kernel = (!tracers && !sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
+                : (!tracers && sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KShebaSites>
+                : (!tracers && !sites && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
                      hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active, hp->bgc, hp->bgc_bot, hp->bfl, hp->out_bgc,
