@@ -153,9 +153,11 @@ struct Col {
 // density constants; getT: /S_br and /S_br**2; S_abs/m and H_abs/m; H/c_l; the constant kappa_l*mu), each within 1-2 ulp of the
 // quotient the reference forms -- the parity bar is 1e-6 relative.  With the loads pipelined the sweeps are bound by their
 // dependent FP64 chains, and an IEEE division is an 11-instruction chain: 67.5 ms per launch of the default bench with the
-// shared reciprocals, 73.1 ms with the reference's quotients (=0).
+// shared reciprocals, 73.1 ms with the reference's quotients (=0).  Levels 2 and 3 (default) change no bits any more: they form
+// the reciprocals (2) and the other quotients of the fused sweeps (3) by the compiler's own Newton sequence without the operand
+// scaling and special-case fix-up around it, see recip() / quot(): 65.4 -> 63.4 ms (same box).
 #ifndef SAMSIM_FAST_DIV
-#define SAMSIM_FAST_DIV 1
+#define SAMSIM_FAST_DIV 3
 #endif
 // SAMSIM_HORNER: the liquidus polynomial in Horner form (5 operations instead of 9 per evaluation, about six evaluations per
 // layer-cell; 1 % on the default bench); 0 = the reference's c2*T + c3*T**2 + c4*T**3
@@ -192,12 +194,39 @@ __device__ __forceinline__ int wave_max(int v) {
   return m;
 }
 
+// SAMSIM_FAST_DIV 2: 1/x as the compiler's own division sequence forms it -- v_rcp_f64 and three Newton steps -- without the
+// operand scaling and the special-case fix-up around it (v_div_scale x2, v_div_fmas, v_div_fixup): the divisors are normal-range
+// numbers (m, thick, S_br, ...), for which both give the same bits (tools/div_probe.hip checks 2^26 operands on the GPU)
+__device__ __forceinline__ double recip(double x) {
+#if SAMSIM_FAST_DIV >= 2
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+// SAMSIM_FAST_DIV 3: the other quotients of the two fused sweeps the same way (two Newton steps, a*r, one residual correction: the
+// arithmetic of the compiler's sequence, 8 instructions instead of 11)
+__device__ __forceinline__ double quot(double a, double b) {
+#if SAMSIM_FAST_DIV >= 3
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#else
+  return a / b;
+#endif
+}
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 // S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594
 __device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
 #if SAMSIM_FAST_DIV
-  const double rm = 1.0 / m;
+  const double rm = recip(m);
   S_bu = S_abs * rm;
   H = H_abs * rm;
 #else
@@ -234,7 +263,7 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
                                              double &f, double &ddT_f) {
 #if SAMSIM_FAST_DIV
   if (sb > 0.0001) {  // neither clamp is active: one reciprocal serves both quotients
-    const double inv = 1.0 / sb;
+    const double inv = recip(sb);
     f = -latent_heat - H + latent_heat * S_bu * inv + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
     ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) * (inv * inv);
     return;
@@ -264,7 +293,7 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
     T_0 = T_in;
     sb = S_br_poly(s, T_0);
     newton_terms(s, H, S_bu, T_0, sb, 0.000000001, f, ddT_f);
-    T = T_0 - f / ddT_f;
+    T = T_0 - quot(f, ddT_f);
     int i = 0;
     while (fabs(f) > 1.0) {
       T_0 = T;
@@ -283,10 +312,10 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
       }
       sb = S_br_poly(s, T_0);
       newton_terms(s, H, S_bu, T_0, sb, 0.0000000001, f, ddT_f);
-      T = T_0 - f / ddT_f;
+      T = T_0 - quot(f, ddT_f);
       if (++i == 260) { rc = 99; break; }
     }
-    phi = 1.0 - S_bu / S_br_clamped(s, T, S_bu);
+    phi = 1.0 - quot(S_bu, S_br_clamped(s, T, S_bu));
   } else if (S_bu < 0.001) {
     if (H > 0.0) { phi = 0.0; T = H / c_l; }
     else if (H <= -latent_heat) { phi = 1.0; T = (H + latent_heat) / c_s; }
@@ -303,7 +332,7 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
 // with (mo_thermo_functions.f90:84,129,131-143): same operands, same operations, so the same phi bit for bit.  The down sweeps
 // use it instead of loading phi (one array less to hand over).
 __device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_bu, double S_br_T) {
-  if (S_br_clamped(s, T_liquid(H), S_bu) > S_bu && S_bu > 0.001) return 1.0 - S_bu / S_br_T;
+  if (S_br_clamped(s, T_liquid(H), S_bu) > S_bu && S_bu > 0.001) return 1.0 - quot(S_bu, S_br_T);
   if (S_bu < 0.001) {
     if (H > 0.0) return 0.0;
     if (H <= -latent_heat) return 1.0;
@@ -630,7 +659,7 @@ struct Expelled { double psi_s, psi_l, psi_g, V_ex; };
 __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m) {
   Expelled e;
 #if SAMSIM_FAST_DIV
-  const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l), rth = 1.0 / thick;
+  const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l), rth = recip(thick);
   e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
   e.psi_s = V_s * rth;
   e.psi_l = (V_l - e.V_ex) * rth;
@@ -669,12 +698,12 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
     } else {
       const double height = r.st + r.bot;  // thick(k+1..Na-1) + bottom part
       r.minp = dmin(r.minp, perm);
-      r.stp = r.stp + thick / perm;
+      r.stp = r.stp + quot(thick, perm);
       r.st = r.st + thick;
       double ray;
       const double d_S_br = S_br - r.S_br_bot;
       if (CFG(harmonic_flag) == 2) {
-        const double hp = (r.minp < x.p14) ? 0.0 : (r.st + r.bot) / (r.stp + r.botterm);
+        const double hp = (r.minp < x.p14) ? 0.0 : quot(r.st + r.bot, r.stp + r.botterm);
         ray = grav_f * rho_l * bbeta * d_S_br * height * hp;
       } else {
         ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(r.minp, r.perm_bot);
@@ -1190,7 +1219,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
       LAY(SAMSIM_A_PSI_G, j) = psi_g;
     }
-    if (j >= 2) LAY(D_HR, j) = thick / (2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
+    if (j >= 2) LAY(D_HR, j) = quot(thick, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
     m = m + flm_next - flm_j;
     if (flm_next < 0.0) {
       H_abs = H_abs + flm_next * T * c_l;
@@ -1200,7 +1229,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       H_abs = H_abs - flm_j * T_up * c_l;
       S_abs = S_abs - dmax(flm_j * S_br_up, -S_abs_up);
     }
-    const double S_bu = S_abs / m;  // refreshed bulk salinity, mo_grotz.f90:333-335
+    const double S_bu = quot(S_abs, m);  // refreshed bulk salinity, mo_grotz.f90:333-335
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_j = flm_next;
     if (j == Na) {
@@ -1437,7 +1466,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       hr_u = (k > 2) ? LAY(D_HR, k - 1) : hr_top;
       H_u = LAY(SAMSIM_A_H_ABS, k - 1); m_u = LAY(SAMSIM_A_M, k - 1); S_u = LAY(SAMSIM_A_S_ABS, k - 1);
       const double R = hr_u + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
-      flq_k = (T_k - T_u) / R;
+      flq_k = quot(T_k - T_u, R);
     } else {
       flq_k = c.fl_Q1;
     }
