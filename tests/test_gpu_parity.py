@@ -10,7 +10,7 @@ import pytest
 import samsim_amd
 from samsim_amd import testcases as tcs
 from samsim_amd.capi import SCALARS
-from tests.helpers import RTOL, assert_state_close, golden, load_checkpoint, rel_err, sheba_forcing
+from tests.helpers import ROOT, RTOL, assert_state_close, golden, load_checkpoint, rel_err, sheba_forcing
 from tests.oracle_lib import oracle_solver
 
 pytestmark = pytest.mark.gpu
@@ -213,6 +213,19 @@ def test_failed_columns_are_frozen_and_reported():
     a, b = g.get_state(), o.get_state()
     for n in ["H_abs", "S_abs", "T"]:
         assert rel_err(a.arr(n)[:, healthy], b.arr(n)[:, healthy]) <= RTOL
+
+
+def test_division_sequences_return_ieee_quotients():
+    """samsim_div.h forms 1/x and a/b of the fused sweeps by the compiler's Newton sequence without operand scaling and
+    special-case fix-up; tools/div_probe (built by __graft_entry__.build()) compares them with 1.0/x and a/b on 2^26
+    operand pairs over 1e-12..1e12: no bit may differ"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "div_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "samsim_amd", "csrc"), "div_probe"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "recip != 1.0/x: 0 " in out.stdout and out.stdout.rstrip().endswith("quot != a/b: 0"), out.stdout
 
 
 def test_unsupported_flags_are_rejected():

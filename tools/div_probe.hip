@@ -1,25 +1,13 @@
-// div_probe.hip -- are recip(x) / quot(a, b) of samsim_kernels.hip (SAMSIM_FAST_DIV 2, 3: v_rcp_f64 + Newton steps, the arithmetic
-// of the compiler's own FP64 division sequence without operand scaling and special-case fix-up) the same bits as 1.0/x and a/b?
+// div_probe.hip -- are recip(x) / quot(a, b) of samsim_amd/csrc/samsim_div.h (SAMSIM_FAST_DIV 2, 3: v_rcp_f64 + Newton steps, the
+// arithmetic of the compiler's own FP64 division sequence without operand scaling and special-case fix-up) the same bits as 1.0/x and a/b?
 // 2^26 pseudo-random operand pairs over the magnitudes the sweeps divide by (1e-12 .. 1e12, both signs), counted on the GPU.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/div_probe.hip -o tools/div_probe && tools/div_probe
+//   make -C samsim_amd/csrc div_probe && tools/div_probe   (tests/test_gpu_parity.py runs it)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 
-__device__ __forceinline__ double recip(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double quot(double a, double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  const double q = a * r;
-  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
-}
+#include "../samsim_amd/csrc/samsim_div.h"
+
 __device__ __forceinline__ uint64_t mix(uint64_t z) {  // splitmix64
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
