@@ -59,7 +59,7 @@ CONTAINS
     cfg%k_snow_flush = 0.75_wp; cfg%max_flux_plate = 10000.0_wp
   END SUBROUTINE default_flags
 
-  !> per-testcase settings and initial state: testcases 1 (mo_init.f90:865-945), 3 (:1045-1080), 4 (:1127-1207),
+  !> per-testcase settings and initial state: testcases 1 (mo_init.f90:865-945), 2/6/9/33/34 (tanks), 3 (:1045-1080), 4 (:1127-1207),
   !! 5 (:1210-1273) and 7 (:1360-1395); common tail mo_init.f90:1981-2031.  Namelist group &samsim_flags (unit nml_unit, if > 0) overrides the settings.
   SUBROUTINE init(testcase, nml_unit)
     INTEGER, INTENT(in) :: testcase, nml_unit
@@ -87,8 +87,8 @@ CONTAINS
        cfg%snow_flush_flag = 1; cfg%flush_heat_flag = 2; cfg%snow_precip_flag = 1
        cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
        cfg%thick_0 = 0.01_wp; cfg%time_out = 86400._wp; cfg%time_total = cfg%time_out*365._wp*4.5_wp; cfg%dt = 10._wp
-    ELSE IF (testcase == 2 .OR. testcase == 6 .OR. testcase == 9) THEN
-       ! tank experiments, mo_init.f90:948-1003, 1278-1330, 1684-1740 (bgc off)
+    ELSE IF (testcase == 2 .OR. testcase == 6 .OR. testcase == 9 .OR. testcase == 33 .OR. testcase == 34) THEN
+       ! tank experiments, mo_init.f90:948-1003, 1278-1330, 1684-1740, 1779-1873, 1876-1970 (bgc off)
        cfg%tank_flag = 2; cfg%boundflux_flag = 3; cfg%grav_heat_flag = 1
        cfg%alpha_flux_instable = 22.0_wp
        IF (testcase == 2) THEN
@@ -101,6 +101,15 @@ CONTAINS
           cfg%nlayer = 40; cfg%n_bottom = 3; cfg%n_top = 3
           T2m = -18._wp; T_top = -18._wp; cfg%T_bottom = 0.0_wp; cfg%S_bu_bottom = 31.2_wp
           cfg%thick_0 = 0.0025_wp; cfg%time_out = 1800._wp/2._wp; cfg%time_total = cfg%time_out*39._wp*2._wp*2._wp; cfg%dt = 0.5
+       ELSE IF (testcase == 33 .OR. testcase == 34) THEN
+          fl_q_bottom = 10._wp; cfg%alpha_flux_stable = 15._wp; tank_depth = 0.94_wp
+          cfg%nlayer = 100; cfg%n_bottom = 10; cfg%n_top = 3
+          T2m = -15._wp; T_top = -10._wp; cfg%T_bottom = 0.5_wp; cfg%thick_0 = 0.005_wp; cfg%dt = 10._wp
+          IF (testcase == 33) THEN
+             cfg%S_bu_bottom = 0.13_wp; cfg%time_out = 60._wp*5._wp; cfg%time_total = cfg%time_out*12._wp*6._wp
+          ELSE
+             cfg%S_bu_bottom = 34.9_wp; cfg%time_out = 60._wp*10._wp; cfg%time_total = 86400._wp*10._wp
+          END IF
        ELSE
           fl_q_bottom = 10._wp; cfg%alpha_flux_stable = 15._wp; tank_depth = 0.8_wp
           cfg%nlayer = 100; cfg%n_bottom = 10; cfg%n_top = 3

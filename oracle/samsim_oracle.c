@@ -293,6 +293,12 @@ static void sub_test9(double time, double *T2m) {
   else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) *T2m = -15.0;
   else *T2m = 1.0;
 }
+static void sub_test34(double time, double *T2m) {                                   /* mo_testcase_specifics.f90:146-162 */
+  if (time < 2.0 * 3600.0) *T2m = 0.0;
+  else if (time < 86400.0 * 5.0) *T2m = -15.0;
+  else if (time < 86400.0 * 7.0) *T2m = -5.0;
+  else *T2m = 1.0;
+}
 static void sub_test6(double time, double *T2m) {
   static const double t[8] = {1714.0, 1676.0, 1525.0, 1483.0, 1385.0, 1349.0, 1160.0, 1100.0};
   static const double v[8] = {-19.0, -5.0, -18.0, -5.0, -18.0, -5.0, -18.0, -5.0};
@@ -1557,6 +1563,7 @@ static void step_part_b(column *c) {
   else if (g->testcase == 2) sub_test2(c->time, &c->T2m);
   else if (g->testcase == 6) sub_test6(c->time, &c->T2m);
   else if (g->testcase == 9) sub_test9(c->time, &c->T2m);
+  else if (g->testcase == 34) sub_test34(c->time, &c->T2m);
 
   /* tank: the water below the ice holds what salt the ice does not, mo_grotz.f90:573-575 */
   if (g->tank_flag == 2) {

@@ -2059,6 +2059,11 @@ __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g,
     if (time < 19.75 * 3600.0) c.T2m = 0.0;
     else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) c.T2m = -15.0;
     else c.T2m = 1.0;
+  } else if (K::general && CFG(testcase) == 34) {  // sub_test34, :146-162
+    if (time < 2.0 * 3600.0) c.T2m = 0.0;
+    else if (time < 86400.0 * 5.0) c.T2m = -15.0;
+    else if (time < 86400.0 * 7.0) c.T2m = -5.0;
+    else c.T2m = 1.0;
   } else if (K::general && CFG(testcase) == 6) {  // sub_test6, :211-232
     const double t[8] = {1714.0, 1676.0, 1525.0, 1483.0, 1385.0, 1349.0, 1160.0, 1100.0};
     for (int i = 0; i < 8; ++i) {

@@ -161,6 +161,18 @@ def testcase9(ncol: int = 1):
                  3600.0 * 2.0 * 12.0 * 6.0)
 
 
+def testcase33(ncol: int = 1):
+    """mo_init.f90:1779-1873: cooling-chamber experiment on nearly fresh water (S 0.13), 0.94 m tank, constant T2m -15 C"""
+    return _tank(33, ncol, 100, 3, 10, 0.94, 15.0, 10.0, -15.0, -10.0, 0.5, 0.13, 0.005, 10.0, 60.0 * 5.0,
+                 60.0 * 5.0 * 12.0 * 6.0)
+
+
+def testcase34(ncol: int = 1):
+    """mo_init.f90:1876-1975: the same chamber on sea water (S 34.9), ten days with the air temperature of sub_test34
+    (0 C for two hours, -15 C to day 5, -5 C to day 7, then +1 C)"""
+    return _tank(34, ncol, 100, 3, 10, 0.94, 15.0, 10.0, -15.0, -10.0, 0.5, 34.9, 0.005, 10.0, 60.0 * 10.0, 86400.0 * 10.0)
+
+
 def testcase3(ncol: int = 1):
     """mo_init.f90:1045-1080: Notz climatological fluxes (atmoflux 1) + constant snow fall (sub_test3), 20 layers of 3 cm."""
     c = default_config()

@@ -18,6 +18,9 @@ Fixtures are DATA only -- inputs and expected outputs:
   tc5_ref_fullprec.npz      testcase 5 (fixed fluxes, flushing of a 1 m slab), scalars at all 240 output points, layers at every 6th
   tc{2,6,9}_ref_fullprec.npz  the tank experiments (boundflux_flag 3, tank_flag 2; bgc off): scalars (incl. the evolving
                             S_bu_bottom) at all output points, layers at every 4th
+  tc{33,34}_ref_fullprec.npz  the cooling-chamber set-ups of init(33) (nearly fresh water, constant air temperature) and
+                            init(34) (sea water, sub_test34's ten-day freeze / warm-up schedule): scalars at all output points
+                            (70 and 1417), layers at every 4th / 48th
   tc{1,2,6}_bgc_ref.npz     the passive tracers of the testcases that ship with bgc_flag 2: bgc_abs and bgc_bottom at every
                             output point (float64); the committed dat_bgc0{1,2}.{bu,br}.dat of testcase 1 are in
                             tc1_reference_dat.npz
@@ -166,6 +169,14 @@ def main():
         recs = cached(tc, f"tc{tc}_dump.bin", {"SAMSIM_REF_BGC": "0"})
         d = pack(recs[3::4])
         d["index"] = np.arange(len(recs))[3::4]
+        for k, v in pack(recs, with_layers=False).items():
+            d["all_" + k] = v
+        np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
+    # --- testcases 33 / 34 (cooling-chamber tank set-ups, bgc off as shipped): all output points, layers at every 4th / 48th
+    for tc, every in ((33, 4), (34, 48)):
+        recs = cached(tc, f"tc{tc}_dump.bin")
+        d = pack(recs[every - 1::every])
+        d["index"] = np.arange(len(recs))[every - 1::every]
         for k, v in pack(recs, with_layers=False).items():
             d["all_" + k] = v
         np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)

@@ -129,6 +129,16 @@ def test_fortran_host_tank_experiment(tmp_path):
         assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc9 output {i}"
     s = (tmp_path / "output" / "dat_settings.dat").read_text()
     assert "tank_flag               2" in s and "boundflux_flag          3" in s
+    # init(33): the cooling chamber on nearly fresh water
+    d33 = tmp_path / "tc33"
+    d33.mkdir()
+    run_host(d33, "&samsim_run testcase=33, ncol=8 /\n")
+    ref = golden("tc33_ref_fullprec.npz")
+    T = load(d33, "T")
+    assert T.shape[0] == len(ref["all_step"])
+    for j, i in enumerate(ref["index"]):
+        na = int(ref["all_N_active"][i])
+        assert np.abs(T[i, :na] - ref["a_T"][j, :na]).max() <= 1.5e-3, f"tc33 output {i}"
 
 
 @pytest.mark.skipif(not os.path.exists(HOST), reason="Fortran host not built (no flang)")

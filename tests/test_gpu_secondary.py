@@ -136,9 +136,9 @@ def test_tc7_simple_parametrisations_free_run_and_reference_windows():
         _check(g, o, f"tc7 window {idx}")
 
 
-@pytest.mark.parametrize("tc,nout", [(2, 120), (9, 72), (6, 60)])
+@pytest.mark.parametrize("tc,nout", [(2, 120), (9, 72), (6, 60), (33, 70), (34, 1417)])
 def test_tank_experiments(tc, nout):
-    """testcases 2, 6, 9 (boundflux_flag 3, tank_flag 2, T2m schedules): the HIP path's output snapshots against the
+    """testcases 2, 6, 9, 33, 34 (boundflux_flag 3, tank_flag 2, T2m schedules): the HIP path's output snapshots against the
     reference's own records and, at the end, the full state against the oracle; the water below the ice gets saltier"""
     ncol = 8
     cfg, st = getattr(tcs, f"testcase{tc}")(ncol)
