@@ -123,6 +123,13 @@ CONTAINS
        cfg%T_bottom = -1.0_wp; cfg%S_bu_bottom = 34._wp
        cfg%thick_0 = 0.03_wp; cfg%time_out = 86400._wp*3.5_wp; cfg%time_total = cfg%time_out*54._wp*2._wp*2._wp
        cfg%dt = 60._wp
+    ELSE IF (testcase == 50) THEN
+       ! mo_init.f90:1497-1531: the reference's default flags with boundflux_flag 2, 70 layers, three years of growth
+       cfg%nlayer = 70; cfg%n_top = 5; cfg%n_bottom = 5
+       cfg%boundflux_flag = 2
+       fl_q_bottom = 20._wp; T_top = -20._wp
+       cfg%T_bottom = -1.72_wp; cfg%S_bu_bottom = 34._wp
+       cfg%thick_0 = 0.005_wp; cfg%time_out = 3600._wp*24._wp*30._wp; cfg%time_total = cfg%time_out*12._wp*3._wp; cfg%dt = 10._wp
     ELSE IF (testcase == 5) THEN
        cfg%nlayer = 100; cfg%n_top = 20; cfg%n_bottom = 10
        cfg%boundflux_flag = 2; cfg%atmoflux_flag = 3; cfg%flush_heat_flag = 2; cfg%flush_flag = 5
@@ -217,7 +224,7 @@ CONTAINS
        lay(:, 1, A_THICK) = cfg%thick_0
        lay(:, 1, A_M) = lay(:, 1, A_THICK)*rho_l
        lay(:, 1, A_S_ABS) = cfg%S_bu_bottom*lay(:, 1, A_M)
-       IF (testcase == 1) THEN
+       IF (testcase == 1 .OR. testcase == 50) THEN
           lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom*c_l
        ELSE IF (cfg%tank_flag == 2) THEN
           lay(:, 1, A_H_ABS) = lay(:, 1, A_M)*cfg%T_bottom          ! as written in mo_init.f90:1002

@@ -173,6 +173,28 @@ def testcase34(ncol: int = 1):
     return _tank(34, ncol, 100, 3, 10, 0.94, 15.0, 10.0, -15.0, -10.0, 0.5, 34.9, 0.005, 10.0, 60.0 * 10.0, 86400.0 * 10.0)
 
 
+def testcase50(ncol: int = 1):
+    """mo_init.f90:1497-1531: three years of growth under the Notz climatological fluxes from 5 mm of sea water, 70 layers;
+    the spin-up of the convection study of Griewank & Notz 2012 (the reference's defaults otherwise: atmoflux_flag 1,
+    boundflux_flag 2, gravity drainage, flushing, flooding)"""
+    c = default_config()
+    c.testcase = 50
+    c.nlayer, c.n_top, c.n_bottom = 70, 5, 5
+    c.atmoflux_flag, c.precip_flag, c.boundflux_flag = 1, 0, 2
+    c.T_bottom, c.S_bu_bottom = -1.72, 34.0
+    c.thick_0, c.dt, c.time_out = 0.005, 10.0, 3600.0 * 24.0 * 30.0
+    c.time_total = c.time_out * 12.0 * 3.0
+    _finish(c)
+    st = _blank_state(c, ncol)
+    st.sc("fl_q_bottom")[:] = 20.0
+    st.sc("T_top")[:] = -20.0
+    st.arr("thick")[0] = c.thick_0
+    st.arr("m")[0] = st.arr("thick")[0] * RHO_L
+    st.arr("S_abs")[0] = c.S_bu_bottom * st.arr("m")[0]
+    st.arr("H_abs")[0] = st.arr("m")[0] * c.T_bottom * C_L
+    return c, st
+
+
 def testcase3(ncol: int = 1):
     """mo_init.f90:1045-1080: Notz climatological fluxes (atmoflux 1) + constant snow fall (sub_test3), 20 layers of 3 cm."""
     c = default_config()

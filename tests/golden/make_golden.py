@@ -21,6 +21,8 @@ Fixtures are DATA only -- inputs and expected outputs:
   tc{33,34}_ref_fullprec.npz  the cooling-chamber set-ups of init(33) (nearly fresh water, constant air temperature) and
                             init(34) (sea water, sub_test34's ten-day freeze / warm-up schedule): scalars at all output points
                             (70 and 1417), layers at every 4th / 48th
+  tc50_ref_fullprec.npz     init(50) (70 layers, reference default flags, Notz fluxes): the first 6 output points (150 days,
+                            all 70 layers active from the second on)
   tc{1,2,6}_bgc_ref.npz     the passive tracers of the testcases that ship with bgc_flag 2: bgc_abs and bgc_bottom at every
                             output point (float64); the committed dat_bgc0{1,2}.{bu,br}.dat of testcase 1 are in
                             tc1_reference_dat.npz
@@ -180,6 +182,8 @@ def main():
         for k, v in pack(recs, with_layers=False).items():
             d["all_" + k] = v
         np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
+    # --- testcase 50 (three years of growth under the Notz fluxes on the reference's default flags): the first 6 output points
+    np.savez_compressed(os.path.join(OUT, "tc50_ref_fullprec.npz"), **pack(cached(50, "tc50_dump.bin", {"SAMSIM_REF_MAXSTEPS": "1300000"})))
     # --- forcing of other ERA-interim sites: three more sets of tables, and the reference on the North Pole set
     d = {}
     for site in ("NorthPole-p2", "barrow-p2", "70N00W-p2"):

@@ -185,6 +185,20 @@ def test_tc3_notz_fluxes_and_snowfall_bitwise():
     assert not o.get_status()[0].any()
 
 
+def test_tc50_default_flags_growth_bitwise():
+    """init(50): the reference's default flag set (atmoflux_flag 1, boundflux_flag 2, gravity drainage, flush3, flooding) on 70
+    layers from 5 mm of sea water; the first 6 output points (1.3 million steps; every layer active from the second on)"""
+    cfg, st = tcs.testcase50(1)
+    o = oracle_solver(cfg, 1)
+    o.set_state(st)
+    o.set_clock()
+    ref = golden("tc50_ref_fullprec.npz")
+    assert len(ref["step"]) == 6 and ref["N_active"][-1] == 70
+    for i in range(6):
+        _compare_output(o.run_to_output(), ref, i, i, f"tc50 output {i}", prefix="")
+    assert not o.get_status()[0].any()
+
+
 def test_tc5_fixed_flux_flushing_bitwise():
     """testcase 5 (atmoflux_flag 3, all layers active from the start, salinity reset at step 2, flushing only): scalars at
     all 240 output points, per-layer state at every 6th"""
