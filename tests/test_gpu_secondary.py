@@ -268,3 +268,28 @@ def test_flag_variants_against_reference_records(tc, variant, nout):
         assert ref["a_S_bu"][rows[max(i for i in rows if i < nout)], 1] < 1e-3           # flush4 is rinsing the upper layers
     if tc == 7:
         assert ref["all_N_active"][nout - 1] > 15     # past the 0.15 m the lower branch of the profile spans
+
+
+def test_tc50_default_flags_against_reference_records():
+    """init(50): the reference's default flag set on 70 layers from 5 mm of sea water; the HIP path's first four output points
+    (step 1, days 30, 60 and 90: open water, then all 70 layers active) against the reference's own records, then the state
+    against the oracle"""
+    cfg, st = tcs.testcase50(1)
+    g = samsim_amd.hip_solver(cfg, 1)
+    o = oracle_solver(cfg, 1)
+    for s in (g, o):
+        s.set_state(st)
+        s.set_clock()
+    g.set_output_window(0, 1)
+    ref = golden("tc50_ref_fullprec.npz")
+    for i in range(4):
+        out = g.run_to_output()
+        assert out.step == ref["step"][i] and out.n_active[0] == ref["N_active"][i], f"output {i}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick"]:
+            assert rel_err(out.arr(n)[:na, 0], ref["a_" + n][i, :na], 1e-7) <= RTOL, f"output {i}: {n} vs reference"
+        for n, floor in (("T_top", 1e-2), ("freeboard", 1e-7), ("thickness", 1e-7)):
+            assert rel_err(out.sc(n)[0], ref["s_" + n][i], floor) <= RTOL, f"output {i}: {n} vs reference"
+    assert ref["N_active"][3] == 70 and not g.get_status()[0].any()
+    o.step(g.get_clock().step)
+    _check(g, o, "tc50 day 90")
