@@ -21,6 +21,7 @@
 !!   SAMSIM_REF_BGC        0 -> sets bgc_flag=1 (tracers off; T/phi/S are unaffected, SURVEY.md 2 row 9)
 !!   SAMSIM_REF_TRACE_FROM / SAMSIM_REF_TRACE_TO   step window (inclusive) of per-step trace records
 !!   SAMSIM_REF_QUIET      1 -> no dump at all (timing runs)
+!!   SAMSIM_REF_INIT       1 -> a first record of kind 3 holds the state init(testcase) left (initial profiles typed into init)
 !!   SAMSIM_REF_FLUSH / _GRAV / _FLOOD / _PRESCRIBE   override flush_flag, grav_flag, flood_flag, prescribe_flag after init
 MODULE mo_output
 
@@ -221,6 +222,8 @@ CONTAINS
        CALL GET_ENVIRONMENT_VARIABLE('SAMSIM_REF_DUMP', path, length, stat)
        IF (stat /= 0 .OR. length == 0) path = './ref_dump.bin'
        OPEN(dump_unit, file=TRIM(path), STATUS='replace', ACCESS='stream', FORM='unformatted')
+       CALL env_int('SAMSIM_REF_INIT', v, found)          ! 1 -> first record (kind 3) = the state init(testcase) left
+       IF (found .AND. v == 1) CALL dump_record(3)
     END IF
   END SUBROUTINE output_begin
 

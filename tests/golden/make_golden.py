@@ -23,6 +23,9 @@ Fixtures are DATA only -- inputs and expected outputs:
                             (70 and 1417), layers at every 4th / 48th
   tc50_ref_fullprec.npz     init(50) (70 layers, reference default flags, Notz fluxes): the first 6 output points (150 days,
                             all 70 layers active from the second on)
+  tc51_ref_fullprec.npz     init(51) (turb_flag 1, 70 layers of uneven thickness active from the start): the state init left, as the
+                            reference itself dumps it before the first step, scalars at the first 222 output points, layers at
+                            every 13th
   tc{1,2,6}_bgc_ref.npz     the passive tracers of the testcases that ship with bgc_flag 2: bgc_abs and bgc_bottom at every
                             output point (float64); the committed dat_bgc0{1,2}.{bu,br}.dat of testcase 1 are in
                             tc1_reference_dat.npz
@@ -184,6 +187,17 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"tc{tc}_ref_fullprec.npz"), **d)
     # --- testcase 50 (three years of growth under the Notz fluxes on the reference's default flags): the first 6 output points
     np.savez_compressed(os.path.join(OUT, "tc50_ref_fullprec.npz"), **pack(cached(50, "tc50_dump.bin", {"SAMSIM_REF_MAXSTEPS": "1300000"})))
+    # --- testcase 51 (starts from a 70-layer profile typed into init): the state init left (record kind 3 of the hook) and the
+    # first 222 output points (80 000 steps)
+    recs = cached(51, "tc51_dump.bin", {"SAMSIM_REF_INIT": "1", "SAMSIM_REF_MAXSTEPS": "80000"})
+    assert recs[0]["kind"] == 3
+    d = pack(recs[1::13])
+    d["index"] = np.arange(len(recs) - 1)[::13]
+    for k, v in pack(recs[1:], with_layers=False).items():
+        d["all_" + k] = v
+    for k, v in pack(recs[:1]).items():
+        d["init_" + k] = v
+    np.savez_compressed(os.path.join(OUT, "tc51_ref_fullprec.npz"), **d)
     # --- forcing of other ERA-interim sites: three more sets of tables, and the reference on the North Pole set
     d = {}
     for site in ("NorthPole-p2", "barrow-p2", "70N00W-p2"):

@@ -199,6 +199,37 @@ def test_tc50_default_flags_growth_bitwise():
     assert not o.get_status()[0].any()
 
 
+def test_tc51_convection_from_a_typed_in_profile_bitwise():
+    """init(51) (Griewank & Notz 2012: boundflux_flag 2, turb_flag 1, gravity drainage, flush3; all 70 layers of uneven
+    thickness active from the start, mo_init.f90:1534-1681).  The start profile is what the reference's init left (dumped by
+    the hook before the first step, fixture); from it the first 222 output points, bit for bit"""
+    from samsim_amd.testcases import _blank_state, _finish, default_config
+    ref = golden("tc51_ref_fullprec.npz")
+    c = default_config()
+    c.testcase = 51
+    c.nlayer, c.n_top, c.n_bottom = 70, 5, 5
+    c.boundflux_flag, c.turb_flag, c.flush_flag, c.grav_flag = 2, 1, 5, 2
+    c.T_bottom, c.S_bu_bottom = -1.72, 34.0
+    c.thick_0, c.dt, c.time_out = 0.01, 10.0, 3600.0
+    c.time_total = c.time_out * 24.0 * 7.0 * 10.0
+    _finish(c)
+    st = _blank_state(c, 1)
+    for n in ("H_abs", "S_abs", "m", "thick"):
+        st.arr(n)[:, 0] = ref["init_a_" + n][0]
+    st.n_active[:] = int(ref["init_N_active"][0])
+    st.sc("T_top")[:] = ref["init_s_T_top"][0]
+    st.sc("fl_q_bottom")[:] = ref["init_s_fl_q_bottom"][0]
+    assert st.n_active[0] == 70 and ref["init_s_T_top"][0] == -16.7
+    o = oracle_solver(c, 1)
+    o.set_state(st)
+    o.set_clock()
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    assert len(ref["all_step"]) == 222
+    for i in range(222):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"tc51 output {i}")
+    assert not o.get_status()[0].any()
+
+
 def test_tc5_fixed_flux_flushing_bitwise():
     """testcase 5 (atmoflux_flag 3, all layers active from the start, salinity reset at step 2, flushing only): scalars at
     all 240 output points, per-layer state at every 6th"""
