@@ -37,7 +37,8 @@ typedef struct samsim_config {
   int32_t testcase;             /* selects the time-dependent forcing of mo_grotz.f90:503-565:
                                    1 sub_test1 (T_top toggles), 2/6/9/34 sub_test2/6/9/34 (T2m schedule of the
                                    tank experiments), 3 sub_test3 (snow fall), 4/7 sub_test4 (fl_q_bottom),
-                                   5 (S_abs reset at step 2), any other value (0, 33): none            */
+                                   5 (S_abs reset at step 2); 8, 44, 45, 99, 101-105, 111 (lab tables, imposed
+                                   snow) are refused; any other value (0, 33, 50): none               */
   int32_t nlayer, n_top, n_middle, n_bottom;          /* mo_data.f90:62-65                           */
   int32_t atmoflux_flag;        /* 1 Notz climatology, 2 forcing tables, 3 fixed fl_sw / fl_rest     */
   int32_t grav_flag;            /* 1 none, 2 Rayleigh-number gravity drainage, 3 simple              */

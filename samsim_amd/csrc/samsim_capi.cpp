@@ -79,6 +79,9 @@ int validate(const samsim_config &c) {
   if (c.n_top < 3 || c.n_bottom < 1 || c.n_middle < 1 || c.n_top + c.n_middle + c.n_bottom != c.nlayer) return SAMSIM_ERR_ARG;
   if (!(c.dt > 0.0) || !(c.thick_0 > 0.0) || c.i_time_out < 0) return SAMSIM_ERR_ARG;
   auto in = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
+  // testcases whose per-step specifics (mo_grotz.f90:505-565) read the lab's forcing tables or re-impose a snow cover: refused
+  // rather than run without them
+  if (in(c.testcase, {8, 44, 45, 99, 101, 102, 103, 104, 105, 111})) return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.boundflux_flag, {1, 2, 3}) || (c.boundflux_flag == 3 && c.lab_snow_flag != 0)) return SAMSIM_ERR_UNSUPPORTED;
   if (!in(c.atmoflux_flag, {1, 2, 3})) return SAMSIM_ERR_UNSUPPORTED;
   if (c.tank_flag == 2 && !(c.m_total > 0.0)) return SAMSIM_ERR_ARG;

@@ -57,6 +57,22 @@ def test_no_silent_cpu_fallback():
     assert e.value.code == -4
 
 
+def test_unsupported_configurations_are_refused_before_any_device_call():
+    """samsim_create validates the configuration first: flag values and testcases the path does not implement come back as
+    SAMSIM_ERR_UNSUPPORTED (-2) with or without a GPU (a valid one gets as far as the device check)"""
+    for flag, value in (("prescribe_flag", 3), ("flush_flag", 3), ("grav_flag", 4), ("testcase", 99), ("testcase", 103)):
+        cfg, _ = tcs.testcase1(1)
+        setattr(cfg, flag, value)
+        with pytest.raises(samsim_amd.SamsimError) as e:
+            samsim_amd.hip_solver(cfg, 4)
+        assert e.value.code == -2, (flag, value)
+    cfg, _ = tcs.testcase2(1)
+    cfg.lab_snow_flag = 1
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        samsim_amd.hip_solver(cfg, 4)
+    assert e.value.code == -2
+
+
 def test_product_does_not_reference_the_oracle():
     """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
     pkg = os.path.join(ROOT, "samsim_amd")
