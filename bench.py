@@ -4,21 +4,31 @@ column-timesteps/sec, achieved HBM GB/s vs peak).
 
     python bench.py --gpus N --steps K --warmup W
 
-One bench "step" = ONE launch of the hot path that advances every column `--substeps` model time steps
-(a launch is one pass of the time-loop body over the whole resident ensemble, repeated substeps times inside
-the kernel; columns never communicate).  Workload (config.workload): SURVEY.md section 8(d) cfg3 -- testcase 4 /
-SHEBA physics and forcing tables (boundflux 2, gravity drainage, flushing, flooding, snow), `--ncol` columns per
-GPU; the initial state tiles a 256-member perturbed ensemble that was spun up 200 days from open water (committed
-fixture, tools/make_ensemble_fixture.py), so the lanes of a wave hold genuinely different columns.  The state is resident in HBM before the timed region.
-Multi-GPU: columns are sharded by rank, no data-path collective exists (weak scaling: per-GPU columns fixed).
+One bench "step" = ONE launch of the hot path that advances every column `--substeps` model time steps (a launch is
+one pass of the time-loop body over the whole resident ensemble, repeated substeps times inside the kernel; columns
+never communicate).  Default: 500 time steps per launch, so that the driver's 20 timed launches cover 10 000 time steps
+(SURVEY.md section 8d).  Workload (config.workload): SURVEY.md section 8(d) cfg3 -- testcase 4 / SHEBA physics and
+forcing tables (boundflux 2, gravity drainage, flushing, flooding, snow), `--ncol` columns per GPU, headline geometry
+Nlayer 80; the initial state tiles a 256-member perturbed ensemble that was spun up 200 days from open water
+(committed fixture), so the lanes of a wave hold genuinely different columns.  State resident in HBM before the timed
+region.
+
+Multi-GPU: columns are sharded by rank, no data-path collective exists (weak scaling: per-GPU columns fixed).  Under
+torchrun the ranks come from RANK / LOCAL_RANK / WORLD_SIZE; a bare `python bench.py --gpus N` (N > 1) starts N fresh
+rank processes itself, before this process has made any GPU call.
 
 The JSON line also carries
   roofline      algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
-  cpu_baseline  the CPU oracle (C port of the reference algorithm) timed on this host on a bounded sample
+  cpu_baseline  the CPU oracle (C port of the reference algorithm) timed on this host: all cores and one core
+  extra         (N = 1) the same geometry started from other stages of the SHEBA year: open water, growth, the melt
+                season (flushing, flooding, regridding: the unfused paths), and the first-300-days rate they imply
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,47 +38,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+# CPU port vs the reference itself (flang -O2, one Xeon core of the build container, testcase 4 from open water,
+# first 3.0e6 steps): oracle 2.32e4 column-timesteps/s, reference 2.58e4
+CALIBRATION_VS_FLANG = 0.90
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def load_checkpoint(name):
-    z = np.load(os.path.join(ROOT, "tests", "golden", name))
+def load_ensemble(name):
     from samsim_amd.capi import State
-    st = State(np.ascontiguousarray(z["lay"]), np.ascontiguousarray(z["scal"]), np.ascontiguousarray(z["n_active"]))
+    z = np.load(os.path.join(GOLDEN, name))
+    st = State(np.ascontiguousarray(z["lay"][:4]), np.ascontiguousarray(z["scal"]), np.ascontiguousarray(z["n_active"]))
     clock = dict(time=float(z["time"]), step=int(z["step"]), n_time_out=int(z["n_time_out"]),
                  time_counter=int(z["time_counter"]), n_outputs=int(z["n_outputs"]))
-    return st, clock
+    pert = (np.ascontiguousarray(z["dT2m"]), np.ascontiguousarray(z["precip_scale"])) if "dT2m" in z.files else None
+    return z, st, clock, pert
+
+
+def sheba_forcing():
+    f = np.load(os.path.join(GOLDEN, "sheba_forcing.npz"))
+    return (f["fl_sw"], f["fl_lw"], f["T2m"], f["precip"])
 
 
 def workload(args):
-    """returns cfg, member states (prognostic arrays, scalars, N_active), per-member perturbation, clock, forcing, name"""
+    """returns cfg, member states (prognostic arrays, scalars, N_active), per-member perturbation, clock, forcing, name, data"""
     from samsim_amd import testcases as tcs
     from samsim_amd.capi import State
     if args.workload == "sheba":
-        z = np.load(os.path.join(ROOT, "tests", "golden", f"sheba_ensemble_{args.nlayer}.npz"))
+        z, st, clock, pert = load_ensemble(f"sheba_ensemble_{args.nlayer}.npz")
         cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
-        st = State(np.ascontiguousarray(z["lay"]), np.ascontiguousarray(z["scal"]), np.ascontiguousarray(z["n_active"]))
-        pert = (np.ascontiguousarray(z["dT2m"]), np.ascontiguousarray(z["precip_scale"]))
-        clock = dict(time=float(z["time"]), step=int(z["step"]), n_time_out=int(z["n_time_out"]),
-                     time_counter=int(z["time_counter"]), n_outputs=int(z["n_outputs"]))
-        f = np.load(os.path.join(ROOT, "tests", "golden", "sheba_forcing.npz"))
-        forcing = (f["fl_sw"], f["fl_lw"], f["T2m"], f["precip"])
+        forcing = sheba_forcing()
         name = (f"SHEBA/testcase-4 physics+forcing (cfg3), {st.ncol}-member perturbed-T2m/precip ensemble spun up 200 days "
                 "from open water (tools/make_ensemble_fixture.py), members tiled over the columns")
+        data = "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; synthetic spun-up ensemble (fixture)"
     elif args.workload == "cfg5":
         cfg, st, clock = tcs.config5(1, nlayer=500)
         st = State(np.ascontiguousarray(st.lay[:4]), st.scal, st.n_active)
         pert = tcs.ensemble_perturbation(4096)
-        f = np.load(os.path.join(ROOT, "tests", "golden", "sheba_forcing.npz"))
-        forcing = (f["fl_sw"], f["fl_lw"], f["T2m"], f["precip"])
+        forcing = sheba_forcing()
         name = ("cfg5: Nlayer 500 (20+460+20), thick_0 4 mm, dt 2 s, synthetic saturated slab + 0.7 m snow, SHEBA forcing from "
                 "day 340, gravity drainage + flooding active")
+        data = ("SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; synthetic saturated slab "
+                "with 0.7 m of snow replicated to all columns (samsim_amd/testcases.py config5)")
     else:
         cfg, _ = tcs.testcase1(1)
-        st, clock = load_checkpoint("tc1_spunup_state.npz")
-        st = State(np.ascontiguousarray(st.lay[:4]), st.scal, st.n_active)
+        _, st, clock, _ = load_ensemble("tc1_spunup_state.npz")
         pert, forcing = None, None
         name = "testcase-1 physics (cfg2), spun-up state replicated to identical columns"
-    return cfg, st, pert, clock, forcing, name
+        data = "synthetic: replicated spun-up testcase-1 state (cooling plate, no forcing tables)"
+    return cfg, st, pert, clock, forcing, name, data
 
 
 def tile(a, n, col0=0):
@@ -89,27 +106,128 @@ def upload_tiled(solver, st, ncol, col0, chunk=65536):
 
 
 def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
-    """oracle (C port of the reference algorithm) on a bounded sample of the same workload"""
+    """oracle (C port of the reference algorithm) on a bounded sample of the same workload: all cores of this process's
+    affinity mask (columns over OpenMP threads), then one core"""
     from samsim_amd.capi import State
     from tests.oracle_lib import oracle_solver
-    # a one-GPU box grants a 16-core CPU share whatever the affinity mask says
-    cores = min(16, len(os.sched_getaffinity(0)))
-    ncol = 4 * cores
-    o = oracle_solver(cfg, ncol)
-    o.set_threads(cores)
-    if forcing is not None:
-        o.set_forcing(*forcing, tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
-    o.set_state(State(tile(st.lay, ncol, col0), tile(st.scal, ncol, col0), tile(st.n_active, ncol, col0).astype(np.int32)))
-    o.set_clock(**clock)
-    t = time.perf_counter()
-    o.step(50)
-    dt = time.perf_counter() - t
-    nsteps = max(50, int(50 * target_s / max(dt, 1e-3)))
-    t = time.perf_counter()
-    o.step(nsteps)
-    dt = time.perf_counter() - t
-    return {"value": ncol * nsteps / dt, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
-            "sample": f"{ncol} columns x {nsteps} steps of the same workload on {cores} OpenMP threads ({dt:.1f} s)"}
+
+    def run(threads, ncol, seconds):
+        o = oracle_solver(cfg, ncol)
+        o.set_threads(threads)
+        if forcing is not None:
+            o.set_forcing(*forcing, tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
+        o.set_state(State(tile(st.lay, ncol, col0), tile(st.scal, ncol, col0), tile(st.n_active, ncol, col0).astype(np.int32)))
+        o.set_clock(**clock)
+        t = time.perf_counter()
+        o.step(50)
+        dt = time.perf_counter() - t
+        nsteps = max(50, int(50 * seconds / max(dt, 1e-3)))
+        t = time.perf_counter()
+        o.step(nsteps)
+        dt = time.perf_counter() - t
+        o.close()
+        return ncol * nsteps / dt, nsteps, dt
+
+    cores = len(os.sched_getaffinity(0))
+    v_all, n_all, t_all = run(cores, 4 * cores, target_s)
+    v_one, n_one, t_one = run(1, 4, 0.5 * target_s)
+    return {"value": v_all, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{4 * cores} columns x {n_all} steps of the same workload on {cores} OpenMP threads ({t_all:.1f} s); "
+                      f"one core: 4 columns x {n_one} steps ({t_one:.1f} s)",
+            "cores_source": "len(os.sched_getaffinity(0))",
+            "one_core": {"value": v_one, "unit": "column-timesteps/s", "cores": 1},
+            "calibration_vs_flang": CALIBRATION_VS_FLANG,
+            "calibration_note": "this port runs at 0.90x the flang -O2 build of the reference itself (same core, testcase 4, "
+                                "first 3.0e6 steps; DESIGN.md section 6)"}
+
+
+def lib_md5():
+    import samsim_amd
+    path = os.environ.get("SAMSIM_HIP_LIB", samsim_amd.HIP_LIB_PATH)
+    with open(path, "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
+
+
+def profiled_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction applied): only quoted when the profiled library is the one loaded now"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None, "profiles/traffic.json missing"
+    e = t.get(key)
+    if not isinstance(e, dict):
+        return None, f"no PMC profile committed for {key}"
+    if e.get("lib_md5") != lib_md5():
+        return None, f"PMC profile {e.get('source')} was taken on another build of the library (md5 differs): not quoted"
+    return e.get("bytes_per_launch"), f"static: {e.get('source')} (same library build, md5 {e.get('lib_md5')[:12]})"
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes, started before this process touches the
+    GPU (it never does); rank 0 prints the JSON line"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def timed_window(g, substeps, launches, warmup, barrier):
+    for _ in range(warmup):
+        g.step(substeps)
+    barrier()
+    work_before, _ = g.get_work()
+    t0 = time.perf_counter()
+    kernel_ms = [g.step_timed(substeps) for _ in range(launches)]
+    barrier()
+    wall = time.perf_counter() - t0
+    work_after, _ = g.get_work()
+    nfail = int((g.get_status()[0] != 0).sum())
+    return wall, kernel_ms, float(work_after - work_before), nfail
+
+
+def stage_windows(g, cfg, args, forcing):
+    """the same geometry started from other stages of the SHEBA year (fixtures made by tests/golden/make_stage_fixtures.py)"""
+    from samsim_amd import testcases as tcs
+    from samsim_amd.capi import State
+    out = {}
+    stages = [("day0_open_water", None)] + [(f"day{d}", f"sheba_ensemble_{args.nlayer}_day{d}.npz") for d in (75, 150, 250, 300, 345, 360)]
+    for name, fixture in stages:
+        if fixture is None:
+            _, st0 = tcs.testcase4(1, nlayer=int(cfg.nlayer), n_top=int(cfg.n_top), n_bottom=int(cfg.n_bottom))
+            st, clock = State(np.ascontiguousarray(st0.lay[:4]), st0.scal, st0.n_active), dict()
+        else:
+            if not os.path.exists(os.path.join(GOLDEN, fixture)):
+                continue
+            _, st, clock, _ = load_ensemble(fixture)
+        upload_tiled(g, st, args.ncol, 0)
+        g.set_clock(**clock)
+        wall, kernel_ms, cells, nfail = timed_window(g, args.substeps, args.extra_launches, 1, g.synchronize)
+        steps = args.extra_launches * args.substeps
+        out[name] = {"column_timesteps_per_s": args.ncol * steps / wall, "layer_cell_updates_per_s": cells / wall,
+                     "timesteps": steps, "mean_launch_ms": float(np.mean(kernel_ms)), "failed_columns": nfail,
+                     "mean_n_active": cells / (args.ncol * steps)}
+    return out
+
+
+def first_300_days(rate_of_stage):
+    """time-weighted rate over days 0-300 from the stage windows (each stage stands for the days around it)"""
+    seg = [("day0_open_water", 0, 40), ("day75", 40, 112), ("day150", 112, 175), ("day200", 175, 225), ("day250", 225, 275),
+           ("day300", 275, 300)]
+    if any(s not in rate_of_stage for s, _, _ in seg):
+        return None
+    t = sum((b - a) / rate_of_stage[s] for s, a, b in seg)
+    return 300.0 / t
 
 
 def main():
@@ -118,35 +236,63 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncol", type=int, default=1 << 20, help="columns per GPU")
-    ap.add_argument("--substeps", type=int, default=20, help="model time steps per launch")
+    ap.add_argument("--substeps", type=int, default=500, help="model time steps per launch")
     ap.add_argument("--workload", choices=["sheba", "tc1", "cfg5"], default="sheba")
     ap.add_argument("--nlayer", type=int, default=80,
                     help="SHEBA geometry: 80 = 20+40+20 (the N_layers BASELINE.json's metric is quoted on) or 100 = 20+60+20 "
                          "(testcase 4 as shipped)")
     ap.add_argument("--sites", type=int, default=1,
                     help="forcing sets (samsim_set_forcing_sites): the tables replicated N times, column c on set c mod N")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the stage windows (open water ... melt season)")
+    ap.add_argument("--extra-launches", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, let them meet (barrier + reductions) and report the sharding without touching a GPU")
+    ap.add_argument("--device-map", default=None,
+                    help="comma-separated HIP device per local rank (default: device = local rank); '0,0' rehearses two ranks "
+                         "on a one-GPU box")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    device = local_rank if args.device_map is None else int(args.device_map.split(",")[local_rank])
     dist = None
     if world > 1:
         # the data path has no collective; ranks only meet for the timing barrier and the max-over-ranks reduction,
         # which run over gloo so that this process holds exactly one GPU runtime (the one the HIP library uses)
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    import samsim_amd
-    from samsim_amd import testcases as tcs
+    if args.dry_run:
+        # the launch plumbing alone: every rank reports its shard, rank 0 prints what a real run would call n_gpus
+        shards = [[rank, device, rank * args.ncol, args.ncol]]
+        if dist is not None:
+            import torch
+            t = torch.zeros(world, 4, dtype=torch.int64)
+            t[rank] = torch.tensor(shards[0])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+            shards = t.tolist()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "shards_rank_device_col0_ncol": shards}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    cfg, st, pert, clock, forcing, wname = workload(args)
+    import samsim_amd
+
+    cfg, st, pert, clock, forcing, wname, data = workload(args)
     ncol = args.ncol
     col0 = rank * ncol
-    g = samsim_amd.hip_solver(cfg, ncol, device=local_rank)
+    g = samsim_amd.hip_solver(cfg, ncol, device=device)
     if forcing is not None and args.sites > 1:
         g.set_forcing_sites(*[np.tile(a, (args.sites, 1)) for a in forcing], (np.arange(ncol) % args.sites).astype(np.int32),
                             tile(pert[0], ncol, col0), tile(pert[1], ncol, col0))
@@ -161,21 +307,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        g.step(args.substeps)
-    barrier()
-    work_before, _ = g.get_work()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        kernel_ms.append(g.step_timed(args.substeps))
-    barrier()
-    wall = time.perf_counter() - t0
-    work_after, _ = g.get_work()
-    status = g.get_status()[0]
-    nfail = int((status != 0).sum())
+    wall, kernel_ms, cells, nfail = timed_window(g, args.substeps, args.steps, args.warmup, barrier)
 
-    wall_max, cells, fails = wall, float(work_after - work_before), float(nfail)
+    wall_max, fails = wall, float(nfail)
     if dist is not None:
         import torch
         t = torch.tensor([wall], dtype=torch.float64)
@@ -192,31 +326,32 @@ def main():
         bytes_per_colstep = 16.0 * (4 * nlayer + 24)   # read + write once of the prognostic state
         mean_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_colstep * ncol * args.substeps / (mean_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE
-        # in separate passes, gfx950 correction applied: profiles/r1_hbm_counter_calibration.txt); None if this
-        # configuration has not been profiled
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get(f"{args.workload}:{ncol}:{nlayer}:{args.substeps}")
-        except OSError:
-            pass
+        traffic, traffic_source = profiled_traffic(f"{args.workload}:{ncol}:{nlayer}:{args.substeps}")
         out = {
             "metric": "column-timesteps/sec", "value": value, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "SHEBA ERA-interim forcing tables (fixture) + synthetic per-column perturbation; synthetic spun-up ensemble (fixture)"
-                    if args.workload == "sheba" else "synthetic: replicated spun-up testcase-1 state",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
             "config": {"workload": wname, "ncol_per_gpu": ncol, "nlayer": nlayer, "timesteps_per_step": args.substeps,
+                       "timed_timesteps": timesteps,
                        "parallelism": f"columns sharded over {world} GPU(s), no collective", "forcing_sites": args.sites},
             "layer_cell_updates_per_s": cells / wall_max,
             "failed_columns": int(fails),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "samsim_step_kernel", "mean_launch_ms": mean_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps},
+                         "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps,
+                         "lib_md5": lib_md5()},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_extra and args.workload == "sheba" and args.sites == 1:
+            ex = stage_windows(g, cfg, args, forcing)
+            rates = {k: v["column_timesteps_per_s"] for k, v in ex.items()}
+            rates["day200"] = value
+            out["extra"] = {"stages": ex,
+                            "melt_season": ex.get("day360") or ex.get("day345"),
+                            "first_300_days": {"column_timesteps_per_s": first_300_days(rates),
+                                               "how": "time-weighted over the stage windows day 0 / 75 / 150 / 200 (headline) / 250 / 300; "
+                                                      "each stage stands for the days around it"}}
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, st, pert, clock, forcing, col0, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:

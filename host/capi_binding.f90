@@ -130,6 +130,14 @@ MODULE mo_samsim_capi
        INTEGER(c_int64_t), INTENT(out) :: step(*)
        INTEGER(c_int32_t), INTENT(out) :: layer(*)
      END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_status(h, status, step, layer, col0, ncols) BIND(C, name='samsim_set_status')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       INTEGER(c_int32_t), INTENT(in) :: status(*)
+       INTEGER(c_int64_t), INTENT(in) :: step(*)
+       INTEGER(c_int32_t), INTENT(in) :: layer(*)
+       INTEGER(c_int64_t), VALUE :: col0, ncols
+     END FUNCTION
      INTEGER(c_int) FUNCTION samsim_set_tracers(h, n_bgc, bgc_bottom, bgc_total) BIND(C, name='samsim_set_tracers')
        IMPORT
        TYPE(c_ptr), VALUE :: h

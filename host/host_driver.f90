@@ -4,7 +4,9 @@
 !! runs on the GPU behind the C-ABI of include/samsim.h for `ncol` columns at once.
 !!
 !! New surface the reference does not have (SURVEY.md, introduction): a namelist file `samsim.nml`
-!!   &samsim_run   testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out, sites /
+!!   &samsim_run   testcase, ncol, col0, ncol_total, device, out_col, perturb, description, max_steps, restart_in, restart_out, sites /
+!! (col0 / ncol_total: this process owns the global columns col0 .. col0+ncol-1 of an ensemble of ncol_total -- one host
+!! process per GPU, contiguous column ranges, no exchange between them, SURVEY.md section 8e)
 !!   &samsim_flags <any flag of mo_data.f90:136-155 or scalar set by mo_init> /       (overrides init(testcase))
 !! `dat_settings.dat` stays the echo of what was actually used.
 !!
@@ -21,7 +23,9 @@ MODULE mo_data
 
   TYPE(samsim_config) :: cfg                 !< every flag / scalar that crosses the C-ABI
   INTEGER             :: testcase_id = 1
-  INTEGER(c_int64_t)  :: ncol = 1            !< number of columns (ensemble size)
+  INTEGER(c_int64_t)  :: ncol = 1            !< number of columns this process holds
+  INTEGER(c_int64_t)  :: col0 = 0            !< global index (0-based) of its first column: perturbation and forcing site follow the global index
+  INTEGER(c_int64_t)  :: ncol_total = -1     !< size of the whole ensemble (echo; default ncol)
   INTEGER             :: device = 0, out_col = 1
   LOGICAL             :: perturb = .FALSE.   !< per-column T2m / precipitation perturbation (SURVEY.md 8d cfg3)
   INTEGER(c_int64_t)  :: max_steps = -1
@@ -281,14 +285,16 @@ CONTAINS
   SUBROUTINE sub_perturbation()
     INTEGER(c_int64_t) :: c, h1, h2
     ALLOCATE(dT2m_col(ncol), precip_scale_col(ncol))
-    DO c = 0, ncol - 1
-       h1 = splitmix64(IEOR(c, INT(z'5A5A2026', c_int64_t)))
+    DO c = 0, ncol - 1          ! counter-based: a function of the GLOBAL column index, whichever process holds the column
+       h1 = splitmix64(IEOR(c + col0, INT(z'5A5A2026', c_int64_t)))
        h2 = splitmix64(h1)
        dT2m_col(c + 1) = -2.0_wp + 4.0_wp*u01(h1)
        precip_scale_col(c + 1) = 1.0_wp + (-0.3_wp + 0.6_wp*u01(h2))
     END DO
-    dT2m_col(1) = 0._wp
-    precip_scale_col(1) = 1._wp
+    IF (col0 == 0) THEN         ! global column 0 stays unperturbed (the reference run)
+       dT2m_col(1) = 0._wp
+       precip_scale_col(1) = 1._wp
+    END IF
   CONTAINS
     FUNCTION splitmix64(x) RESULT(z)
       INTEGER(c_int64_t), INTENT(in) :: x
@@ -382,6 +388,8 @@ CONTAINS
     WRITE(1234, '(A16,I9.0)')  'N_bgc           =', N_bgc
     WRITE(1234, *) '#############  Ensemble (MI355X)  ############'
     WRITE(1234, '(A16,I12)')   'ncol            =', ncol
+    WRITE(1234, '(A16,I12)')   'col0            =', col0
+    WRITE(1234, '(A16,I12)')   'ncol_total      =', MERGE(ncol, ncol_total, ncol_total < 0)
     WRITE(1234, '(A16,I9)')    'out_col         =', out_col
     WRITE(1234, '(A16,L9)')    'perturb         =', perturb
     CLOSE(1234)
@@ -493,7 +501,8 @@ MODULE mo_grotz
   IMPLICIT NONE
 CONTAINS
   !> Binary checkpoint of the resident ensemble (the reference has no restart files; SURVEY.md section 8 f.1).  Same stream
-  !! format as samsim_amd/checkpoint.py: header, then chunks of columns (col0, ncols, lay, scal, n_active).
+  !! format as samsim_amd/checkpoint.py: header, then chunks of columns (col0, ncols, lay, scal, n_active, and -- header word
+  !! has_status = 1 -- the STOP code, layer and step of a frozen column, so that it stays frozen after the restart).
   SUBROUTINE write_restart(h, path)
     TYPE(c_ptr), INTENT(in) :: h
     CHARACTER(len=*), INTENT(in) :: path
@@ -501,16 +510,19 @@ CONTAINS
     TYPE(samsim_state_soa) :: st
     TYPE(samsim_clock)     :: clk
     REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :), bbgc(:, :, :), bbot(:, :)
-    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
+    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:), fstat(:), flay(:)
+    INTEGER(c_int64_t), ALLOCATABLE :: fstep(:)
     INTEGER(c_int64_t) :: c0, n, nb
     INTEGER :: u
     nb = 0
     IF (cfg%bgc_flag == 2) nb = N_bgc
     CALL samsim_check(samsim_get_clock(h, clk), 'samsim_get_clock')
+    ALLOCATE(fstat(ncol), fstep(ncol), flay(ncol))
+    CALL samsim_check(samsim_get_status(h, fstat, fstep, flay), 'samsim_get_status')
     OPEN(NEWUNIT=u, file=TRIM(path), STATUS='replace', ACCESS='stream', FORM='unformatted')
     WRITE(u) restart_magic, ncol, INT(cfg%nlayer, c_int64_t), INT(SAMSIM_NARR, c_int64_t), INT(SAMSIM_NSCAL, c_int64_t), &
          INT(cfg%testcase, c_int64_t), clk%time, clk%step, INT(clk%n_time_out, c_int64_t), INT(clk%time_counter, c_int64_t), &
-         clk%n_outputs, nb, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t
+         clk%n_outputs, nb, 1_c_int64_t, 0_c_int64_t, 0_c_int64_t, 0_c_int64_t
     c0 = 0
     DO WHILE (c0 < ncol)
        n = MIN(chunk, ncol - c0)
@@ -522,6 +534,9 @@ CONTAINS
        WRITE(u) blay
        WRITE(u) bscal
        WRITE(u) bna
+       WRITE(u) fstat(c0 + 1:c0 + n)
+       WRITE(u) flay(c0 + 1:c0 + n)
+       WRITE(u) fstep(c0 + 1:c0 + n)
        DEALLOCATE(blay, bscal, bna)
        IF (nb > 0) THEN                     ! tracer amounts and the concentration of the water below
           ALLOCATE(bbgc(n, cfg%nlayer, nb), bbot(n, nb))
@@ -542,7 +557,8 @@ CONTAINS
     TYPE(samsim_state_soa) :: st
     TYPE(samsim_clock)     :: clk
     REAL(c_double), ALLOCATABLE, TARGET :: blay(:, :, :), bscal(:, :), bbgc(:, :, :), bbot(:, :)
-    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:)
+    INTEGER(c_int32_t), ALLOCATABLE, TARGET :: bna(:), fstat(:), flay(:)
+    INTEGER(c_int64_t), ALLOCATABLE :: fstep(:)
     INTEGER(c_int64_t) :: hdr(6), tail(3), pad(5), c0, n, done, nb
     INTEGER :: u
     nb = 0
@@ -570,6 +586,14 @@ CONTAINS
        st%lay = c_loc(blay); st%scal = c_loc(bscal); st%n_active = c_loc(bna)
        CALL samsim_check(samsim_set_state(h, st, c0), 'samsim_set_state')
        DEALLOCATE(blay, bscal, bna)
+       IF (pad(2) == 1) THEN                ! has_status: set_state cleared the STOP codes, put them back
+          ALLOCATE(fstat(n), flay(n), fstep(n))
+          READ(u) fstat
+          READ(u) flay
+          READ(u) fstep
+          CALL samsim_check(samsim_set_status(h, fstat, fstep, flay, c0, n), 'samsim_set_status')
+          DEALLOCATE(fstat, flay, fstep)
+       END IF
        IF (nb > 0) THEN
           ALLOCATE(bbgc(n, cfg%nlayer, nb), bbot(n, nb))
           READ(u) bbgc
@@ -611,7 +635,7 @@ CONTAINS
        CALL sub_input()
        ALLOCATE(site_of_column(ncol))
        DO n = 1, ncol
-          site_of_column(n) = INT(MOD(n - 1, INT(nsites, c_int64_t)), c_int32_t)
+          site_of_column(n) = INT(MOD(col0 + n - 1, INT(nsites, c_int64_t)), c_int32_t)
        END DO
        IF (perturb) THEN
           CALL sub_perturbation()
@@ -703,7 +727,8 @@ PROGRAM SAMSIM
   INTEGER         :: testcase, ios, nml_unit
   CHARACTER*12000 :: description
   LOGICAL         :: have_nml
-  NAMELIST /samsim_run/ testcase, ncol, device, out_col, perturb, description, max_steps, restart_in, restart_out, sites
+  NAMELIST /samsim_run/ testcase, ncol, col0, ncol_total, device, out_col, perturb, description, max_steps, restart_in, &
+       restart_out, sites
 
   testcase    = 1
   description = 'MI355X-native batched column solver'

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAMSIM_ABI_VERSION 2
+#define SAMSIM_ABI_VERSION 3
 #define SAMSIM_MAX_NLAYER 1024
 
 /* -------- configuration: every flag of mo_data.f90:136-155 plus the scalars mo_init sets -------- */
@@ -137,7 +137,9 @@ typedef struct samsim_output_soa {
 typedef struct samsim_handle samsim_handle;
 
 /* sub_allocate (mo_init.f90:2040-2090) + the flag/scalar part of init (mo_init.f90:83-132, 1981-2031).
- * device: HIP device ordinal.  ncol columns of nlayer layers are allocated on it. */
+ * device: HIP device ordinal.  ncol columns of nlayer layers are allocated on it.  One handle holds at most
+ * nlayer * ncol < 2^29 layer cells (4 GiB per layer array: SAMSIM_ERR_ARG beyond); larger ensembles take several
+ * handles (column ranges), which is also how they are spread over GPUs. */
 int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim_handle **h);
 
 /* sub_input (mo_functions.f90:304-327): 3-hourly tables, time_input(k) = (k-1)*10800 s.
@@ -177,6 +179,11 @@ int samsim_get_output(samsim_handle *h, samsim_output_soa *o);
 /* the reference's STOP codes: status[c] = 0 or code; step/layer of first failure.
  * 9001 is the library's own: an internal hand-over assumption of the fused sweeps did not hold for this column. */
 int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t *layer);
+/* restart only: puts back what samsim_get_status returned for the columns [col0, col0+ncols) (samsim_set_state clears the
+ * status of the columns it uploads), so that a column frozen by a STOP code stays frozen -- and reported -- after a
+ * checkpoint / restart.  step and layer may be NULL. */
+int samsim_set_status(samsim_handle *h, const int32_t *status, const int64_t *step, const int32_t *layer, int64_t col0,
+                      int64_t ncols);
 /* sum over columns of N_active accumulated over all steps taken (layer-cell updates) */
 int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
 

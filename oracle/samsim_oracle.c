@@ -2037,6 +2037,17 @@ int oracle_get_status(oracle_handle *h, int32_t *status, int64_t *step, int32_t 
   return SAMSIM_OK;
 }
 
+/* restart: the checker mirrors samsim_set_status */
+int oracle_set_status(oracle_handle *h, const int32_t *status, const int64_t *step, const int32_t *layer, int64_t col0, int64_t ncols) {
+  if (!h || !status || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  for (int64_t i = 0; i < ncols; i++) {
+    h->cols[col0 + i].status = status[i];
+    if (step) h->cols[col0 + i].err_step = step[i];
+    if (layer) h->cols[col0 + i].err_layer = layer[i];
+  }
+  return SAMSIM_OK;
+}
+
 int oracle_get_work(oracle_handle *h, int64_t *lcu, int64_t *cs) {
   if (!h) return SAMSIM_ERR_ARG;
   int64_t w = 0, s = 0;

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _CFG_INT_FIELDS = [
     "struct_size", "testcase", "nlayer", "n_top", "n_middle", "n_bottom",
@@ -190,6 +190,7 @@ class Solver:
             "set_clock": [vp, C.POINTER(Clock)], "get_clock": [vp, C.POINTER(Clock)],
             "step": [vp, i64], "set_output_window": [vp, i64, i64], "get_output": [vp, C.POINTER(OutputSoA)],
             "get_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
+            "set_status": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), i64, i64],
             "get_work": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
             "get_ensemble_stats": [vp, i32, C.POINTER(C.c_int32), C.POINTER(Stat)],
             "set_tracers": [vp, i32, dp, dp], "set_tracer_state": [vp, dp, i64, i64], "set_tracer_bottom": [vp, dp, i64, i64],
@@ -290,6 +291,14 @@ class Solver:
         ly = np.zeros(self.ncol, dtype=np.int32)
         self._chk(self._f("get_status")(self._h, _ip(st), sp.ctypes.data_as(C.POINTER(C.c_int64)), _ip(ly)), "get_status")
         return st, sp, ly
+
+    def set_status(self, status, step=None, layer=None, col0: int = 0):
+        """restart: put back the STOP codes (and the step / layer of the failure) samsim_get_status returned"""
+        st = np.ascontiguousarray(status, dtype=np.int32)
+        sp = None if step is None else np.ascontiguousarray(step, dtype=np.int64)
+        ly = None if layer is None else np.ascontiguousarray(layer, dtype=np.int32)
+        self._chk(self._f("set_status")(self._h, _ip(st), sp.ctypes.data_as(C.POINTER(C.c_int64)) if sp is not None else None,
+                                        _ip(ly) if ly is not None else None, col0, len(st)), "set_status")
 
     def get_work(self):
         a, b = C.c_int64(), C.c_int64()

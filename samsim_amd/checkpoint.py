@@ -4,8 +4,10 @@ run there always starts from `init(testcase)`).
 The file is a little-endian stream that the Fortran host reads and writes as well (host/host_driver.f90, ACCESS='stream'):
 
     header   int64 magic "SAMCHK01", ncol, nlayer, narr, nscal, testcase,
-             float64 time, int64 step, n_time_out, time_counter, n_outputs, int64 n_bgc, int64 reserved[4]
+             float64 time, int64 step, n_time_out, time_counter, n_outputs, int64 n_bgc, int64 has_status, int64 reserved[3]
     chunks   int64 col0, ncols, then lay[narr][nlayer][ncols], scal[nscal][ncols] (float64), n_active[ncols] (int32),
+             with has_status = 1 (every file written by this version) status[ncols], err_layer[ncols] (int32) and
+             err_step[ncols] (int64): the STOP code of a frozen column and where it failed (samsim_get_status),
              and with tracers (n_bgc > 0) bgc_abs[n_bgc][nlayer][ncols], bgc_bottom[n_bgc][ncols] (float64)
              ... until ncol columns are covered
 
@@ -32,9 +34,10 @@ def save(solver: Solver, path: str, narr: int = NARR, chunk: int = 65536) -> Non
     assert narr in (NARR, NPROG)
     k = solver.get_clock()
     n_bgc = int(getattr(solver, "n_bgc", 0)) if int(solver.cfg.bgc_flag) == 2 else 0
+    status, err_step, err_layer = solver.get_status()
     with open(path, "wb") as f:
         f.write(_HDR.pack(MAGIC, solver.ncol, solver.nlayer, narr, NSCAL, int(solver.cfg.testcase), float(k.time),
-                          int(k.step), int(k.n_time_out), int(k.time_counter), int(k.n_outputs), n_bgc, 0, 0, 0, 0))
+                          int(k.step), int(k.n_time_out), int(k.time_counter), int(k.n_outputs), n_bgc, 1, 0, 0, 0))
         c0 = 0
         while c0 < solver.ncol:
             n = min(chunk, solver.ncol - c0)
@@ -43,6 +46,9 @@ def save(solver: Solver, path: str, narr: int = NARR, chunk: int = 65536) -> Non
             f.write(np.ascontiguousarray(st.lay, dtype="<f8").tobytes())
             f.write(np.ascontiguousarray(st.scal, dtype="<f8").tobytes())
             f.write(np.ascontiguousarray(st.n_active, dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(status[c0:c0 + n], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(err_layer[c0:c0 + n], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(err_step[c0:c0 + n], dtype="<i8").tobytes())
             if n_bgc:
                 a, b = solver.get_tracer_state(c0, n)
                 f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
@@ -56,7 +62,7 @@ def read_header(path: str) -> dict:
     if v[0] != MAGIC:
         raise ValueError(f"{path}: not a SAMSIM checkpoint")
     return dict(ncol=v[1], nlayer=v[2], narr=v[3], nscal=v[4], testcase=v[5], time=v[6], step=v[7], n_time_out=v[8],
-                time_counter=v[9], n_outputs=v[10], n_bgc=v[11])
+                time_counter=v[9], n_outputs=v[10], n_bgc=v[11], has_status=v[12])
 
 
 def load(solver: Solver, path: str) -> dict:
@@ -78,6 +84,11 @@ def load(solver: Solver, path: str) -> dict:
             na = np.frombuffer(f.read(4 * n), dtype="<i4")
             solver.set_state(State(np.ascontiguousarray(lay, dtype=np.float64), np.ascontiguousarray(scal, dtype=np.float64),
                                    np.ascontiguousarray(na, dtype=np.int32)), c0)
+            if h["has_status"]:   # set_state cleared the STOP codes of these columns: frozen columns stay frozen
+                status = np.frombuffer(f.read(4 * n), dtype="<i4")
+                err_layer = np.frombuffer(f.read(4 * n), dtype="<i4")
+                err_step = np.frombuffer(f.read(8 * n), dtype="<i8")
+                solver.set_status(status, err_step, err_layer, c0)
             if n_bgc:
                 a = np.frombuffer(f.read(8 * n_bgc * h["nlayer"] * n), dtype="<f8").reshape(n_bgc, h["nlayer"], n)
                 b = np.frombuffer(f.read(8 * n_bgc * n), dtype="<f8").reshape(n_bgc, n)

@@ -65,6 +65,7 @@ struct samsim_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // uniform clock, mirrored on the host
   samsim_clock clk{};
+  bool stepped = false;        // the kernel has run since the last samsim_set_state: S_bu is refreshed from S_abs / m on get_state
   bool snap_valid = false;
   double snap_time = 0.0;
   long long snap_step = 0;
@@ -98,6 +99,8 @@ int validate(const samsim_config &c) {
 
 template <typename T>
 hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+bool launch_needs_forcing(const samsim_config &c) { return c.atmoflux_flag == 2; }
 
 // ---- ensemble statistics: two passes (mean / min / max, then the squared deviations) over one [ncol] row, columns with a
 // STOP code skipped; fixed grid + tree reduction, so the result does not depend on scheduling
@@ -151,14 +154,15 @@ __global__ void fill_i32(int32_t *dst, size_t n, int32_t v) {
 
 // S_bu(k) = S_abs(k)/m(k) for the active layers: the kernel keeps the bulk salinity in registers only (every reader
 // derives it from S_abs and m), so the array is brought up to date when the host asks for the state
-__global__ void refresh_s_bu(double *lay, const int32_t *n_active, size_t ncol, int N, size_t col0, size_t w) {
+__global__ void refresh_s_bu(double *lay, const int32_t *n_active, const int32_t *status, size_t ncol, int N, size_t col0, size_t w) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w) return;
   const size_t c = col0 + i;
+  if (status[c]) return;   // a column that stopped keeps what it held (its masses may be zero)
   const int na = n_active[c];
   for (int k = 0; k < na; ++k) {
     const double m = lay[((size_t)SAMSIM_A_M * N + k) * ncol + c];
-    lay[((size_t)SAMSIM_A_S_BU * N + k) * ncol + c] = lay[((size_t)SAMSIM_A_S_ABS * N + k) * ncol + c] / m;
+    if (m != 0.0) lay[((size_t)SAMSIM_A_S_BU * N + k) * ncol + c] = lay[((size_t)SAMSIM_A_S_ABS * N + k) * ncol + c] / m;
   }
 }
 
@@ -194,7 +198,9 @@ void advance_clock(samsim_handle *h, long long nsteps) {
 
 int launch(samsim_handle *h, long long nsteps) {
   if (nsteps <= 0) return SAMSIM_OK;
-  if (h->cfg.atmoflux_flag == 2 && h->cfg.boundflux_flag == 2 && !h->f_sw) return SAMSIM_ERR_ARG;
+  // the forcing tables are read whenever atmoflux_flag is 2 (T2m / precipitation in every step, the radiative fluxes with
+  // boundflux_flag 2): no launch without them, whatever the other flags say
+  if (launch_needs_forcing(h->cfg) && (!h->f_sw || !h->f_lw || !h->f_T2m || !h->f_precip || h->flen < 2)) return SAMSIM_ERR_ARG;
   if (h->cfg.bgc_flag == 2 && h->n_bgc < 1) return SAMSIM_ERR_ARG;   // samsim_set_tracers first
   const int s = h->slot;
   h->slot = (h->slot + 1) % kRing;
@@ -217,6 +223,7 @@ int launch(samsim_handle *h, long long nsteps) {
   HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
   HIPCHK(samsim_launch_step(&h->d_params[s], &p, h->stream));
   HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
+  h->stepped = true;
   advance_clock(h, nsteps);
   return SAMSIM_OK;
 }
@@ -257,6 +264,8 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   if (!cfg || !out || ncol <= 0) return SAMSIM_ERR_ARG;
   int rc = validate(*cfg);
   if (rc) return rc;
+  // the kernel addresses a layer array with a 32-bit byte offset (scalar base + one offset register per row)
+  if ((unsigned long long)cfg->nlayer * (unsigned long long)ncol * 8ull >= (1ull << 32)) return SAMSIM_ERR_ARG;
   if (device < 0 || device >= samsim_device_count()) return SAMSIM_ERR_NO_DEVICE;
   HIPCHK(hipSetDevice(device));
   samsim_handle *h = new (std::nothrow) samsim_handle();
@@ -406,9 +415,9 @@ int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
   rc = check_soa(h, s, col0);
   if (rc) return rc;
   const size_t N = (size_t)s->nlayer, nc = (size_t)h->ncol, w = (size_t)s->ncol;
-  if (s->narr == SAMSIM_NARR && h->clk.step > 0) {
-    hipLaunchKernelGGL(refresh_s_bu, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, h->stream, h->lay, h->n_active, nc,
-                       (int)N, (size_t)col0, w);
+  if (s->narr == SAMSIM_NARR && h->stepped) {
+    hipLaunchKernelGGL(refresh_s_bu, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, h->stream, h->lay, h->n_active, h->status,
+                       nc, (int)N, (size_t)col0, w);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -522,12 +531,25 @@ int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t 
   return SAMSIM_OK;
 }
 
+int samsim_set_status(samsim_handle *h, const int32_t *status, const int64_t *step, const int32_t *layer, int64_t col0, int64_t ncols) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (!status || col0 < 0 || ncols < 0 || col0 + ncols > h->ncol) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t w = (size_t)ncols;
+  HIPCHK(hipMemcpy(h->status + col0, status, sizeof(int32_t) * w, hipMemcpyHostToDevice));
+  if (step) HIPCHK(hipMemcpy(h->err_step + col0, step, sizeof(long long) * w, hipMemcpyHostToDevice));
+  if (layer) HIPCHK(hipMemcpy(h->err_layer + col0, layer, sizeof(int32_t) * w, hipMemcpyHostToDevice));
+  return SAMSIM_OK;
+}
+
 int samsim_get_work(samsim_handle *h, int64_t *layer_cell_updates, int64_t *column_steps) {
   int rc = use(h);
   if (rc) return rc;
   const size_t nc = (size_t)h->ncol;
   HIPCHK(hipStreamSynchronize(h->stream));
-  std::vector<long long> w(nc);
+  std::vector<long long> w;
+  try { w.resize(nc); } catch (const std::bad_alloc &) { return SAMSIM_ERR_NOMEM; }
   HIPCHK(hipMemcpy(w.data(), h->work, sizeof(long long) * nc, hipMemcpyDeviceToHost));
   long long tot = 0;
   for (size_t i = 0; i < nc; ++i) tot += w[i];

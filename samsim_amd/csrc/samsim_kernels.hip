@@ -24,7 +24,56 @@
 
 #include "samsim_device.h"
 
+// SAMSIM_STAMPS (profiling builds only, never the product library): 1 = s_memtime stamps around the regions of a time step,
+// summed per wave in LDS and added to g_stamps at the end of the launch; 2 = event counters (Newton evaluations, loop trips).
+// tools/stamps.py reads g_stamps through samsim_debug_stamps.
+#ifndef SAMSIM_STAMPS
+#define SAMSIM_STAMPS 0
+#endif
+// SAMSIM_ISA_MARKS: comment lines in the assembly listing at the boundaries of the hot loops (tools/isa_loops.py --marks)
+#ifdef SAMSIM_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; ISA_MARK " name)
+#else
+#define ISA_MARK(name) ((void)0)
+#endif
+#if SAMSIM_STAMPS
+__device__ unsigned long long g_stamps[32];
+extern "C" int samsim_debug_stamps(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 namespace {
+
+#if SAMSIM_STAMPS
+enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_TAIL,
+       CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
+       CT_DRAIN_LANE, CT_DIRTY };
+struct Stamps {
+  unsigned long long *acc;   // [32] in LDS, one block = one wave
+  unsigned long long t0;
+};
+__device__ __forceinline__ bool st_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
+__device__ __forceinline__ void st_mark(Stamps &st, int region) {
+#if SAMSIM_STAMPS == 1
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  if (st_leader()) st.acc[region] += t - st.t0;
+  st.t0 = t;
+#endif
+}
+__device__ __forceinline__ void st_count(Stamps &st, int counter, unsigned long long n = 1) {
+#if SAMSIM_STAMPS == 2
+  if (st_leader()) st.acc[counter] += n;
+#endif
+}
+#define ST_MARK(r) st_mark(x.st, r)
+#define ST_COUNT(cn, n) st_count(x.st, cn, n)
+#else
+#define ST_MARK(r) ((void)0)
+#define ST_COUNT(cn, n) ((void)0)
+#endif
 
 // ---------------------------------------------------------------- constants, mo_parameters.f90:38-112
 // `pi` and `grav` are default REAL (float32) in the reference (mo_parameters.f90:38-39)
@@ -106,11 +155,24 @@ bool flags_match(const samsim_config &g) {
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) const double gcdouble;
 typedef __attribute__((address_space(1))) int32_t gint32;
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) unsigned long long lu64;
 #else
 typedef double gdouble;
 typedef const double gcdouble;
 typedef int32_t gint32;
+typedef char gchar;
+typedef double ldouble;
+typedef unsigned long long lu64;
 #endif
+// LDS-resident per-column scalars: slot s of lane l is word s*SAMSIM_BLOCK + l of the block's array
+enum lds_slot {
+  LD_grav_drain = 0, LD_grav_salt, LD_grav_temp, LD_melt_out1, LD_melt_out2, LD_melt_out3, LD_melt_err,
+  LD_freeboard, LD_T_freeze, LD_dT2m, LD_precip_scale, LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
+  LD_NSLOT
+};
+#define CL(f) c.ld[LD_##f * SAMSIM_BLOCK]
 
 struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
   double c2, c3, c4, d2, d3, d4;
@@ -118,22 +180,28 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 
 struct Col {
   gdouble *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
-  unsigned col; // this lane's column: 32-bit, so that an access is <scalar row base> + <one 32-bit lane offset>
+  unsigned col; // this lane's column
+  unsigned coff;     // col * 8: byte offset of the column inside a row
+  unsigned rstride;  // UNIFORM ncol * 8: bytes per row
+  size_t astride;    // UNIFORM nlayer * ncol * 8: bytes per layer array
   size_t ncol;
   int N;
   int Na;       // N_active
   int flags;          // COLF_*
-  gdouble *spec;       // [DEV_NSPEC] hand-over block, already offset by the column index
+  gdouble *spec;       // UNIFORM base of the [DEV_NSPEC][ncol] hand-over block
   int status, err_layer;
   long long err_step;
   long long step;  // completed steps; i = step + 1
   // per-column scalars (enum samsim_scalar)
   double m_snow, H_abs_snow, S_abs_snow, thick_snow, psi_s_snow, psi_l_snow, psi_g_snow, T_snow, phi_s;
-  double T_top, melt_thick, T2m, liquid_precip, solid_precip, fl_q_bottom;
-  double grav_drain, grav_salt, grav_temp, melt_out1, melt_out2, melt_out3, melt_err;
-  double freeboard, T_freeze, albedo, fl_sw, fl_lw, melt_thick_snow, fl_Q_snow;
-  double energy_stored, freshwater, total_resist, thickness, bulk_salin;
-  double dT2m, precip_scale;
+  double T_top, melt_thick, fl_q_bottom, melt_thick_snow, fl_Q_snow;
+  // The other per-column scalars live in LDS for the whole launch (CL(name), one 8-byte word per lane and slot, no bank
+  // conflicts): accumulators (grav_*, melt_out*, melt_err), values that are set under conditions and otherwise carried
+  // (freeboard, T_freeze), the forcing of the step (T2m, precipitation, albedo, short- and long-wave flux) and the ensemble
+  // perturbation.  Kept in registers they would be live across both layer loops of every step, where the allocator has no
+  // room for them: they were spilled to scratch memory, i.e. to HBM, around every sweep.
+  ldouble *ld;
+  double energy_stored, freshwater, total_resist, thickness, bulk_salin;  // vital signs: live at output points only
   // per-step temporaries that cross sweeps
   double fl_Q1;      // fl_Q(1)
   double frad;       // fl_rad(N_active)
@@ -144,6 +212,7 @@ struct Col {
   double bgc_flood;  // flood_brine of this step (fl_brine_bgc(N_active,1), mo_flood.f90:140-143)
   bool bgc_grav;     // fl_grav_drain ran this step (its fl_brine_bgc assignment, mo_grav_drain.f90:179)
   bool psi_full;     // this step's down sweep stored psi_s / psi_l / psi_g for every layer (not only for layer 1)
+  bool ray_all;      // this step's first sweep was the full one (sweep_thermo_expulsion): every Rayleigh number of this column is in the array
 };
 
 // Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
@@ -161,11 +230,21 @@ struct Col {
 #endif
 // SAMSIM_HORNER: the liquidus polynomial in Horner form (5 operations instead of 9 per evaluation, about six evaluations per
 // layer-cell; 1 % on the default bench); 0 = the reference's c2*T + c3*T**2 + c4*T**3
+// SAMSIM_DAHEAD: how many layers ahead of the arithmetic the fused down sweep requests its operands (2 or 3)
+#ifndef SAMSIM_DAHEAD
+#define SAMSIM_DAHEAD 2
+#endif
 #ifndef SAMSIM_HORNER
 #define SAMSIM_HORNER 1
 #endif
 #ifndef LAY
-#define LAY(a, k) (c.lay + ((size_t)(a) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
+// Address of element (a, k) = <uniform base of array a> + <32-bit byte offset of (row k, this lane's column)>: the form the
+// hardware loads with a scalar base and ONE 32-bit offset register per row (global_load ... v_off, s[base:base+1]); all arrays
+// of a row share the offset register.  (A 64-bit per-lane address for every array costs two registers each and 64-bit vector
+// arithmetic per access.)  Needs nlayer * ncol * 8 < 4 GiB per handle; samsim_create checks it.
+#define ROWOFF(k) ((unsigned)(((unsigned)((k) - 1)) * c.rstride + c.coff))
+#define LAY(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(a) * c.astride + (size_t)ROWOFF(k)))
+#define SPEC(i) (*(gdouble *)((gchar *)c.spec + (size_t)(unsigned)((unsigned)(i) * c.rstride + c.coff)))
 #endif
 #define STOPC(code, layer)            \
   do {                                \
@@ -193,6 +272,9 @@ __device__ __forceinline__ int wave_max(int v) {
   }
   return m;
 }
+
+// first executing lane of the wave (divergent callers included)
+__device__ __forceinline__ bool wave_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
 
 #include "samsim_div.h"
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
@@ -247,6 +329,35 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
   ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
 }
 
+// SAMSIM_NEWTON1: one division per Newton step of getT instead of two.  With f = N/sb**2 and f' = D/sb**2 (N = A*sb**2 +
+// L*S_bu*sb, D = B*sb**2 - L*S_bu*S_br'(T), A and B the polynomial parts) the step is T_0 - N/D and the stopping rule |f| > 1 reads
+// |N| > sb**2: the same iteration in exact arithmetic, each iterate within an ulp or two of the reference's (like the shared
+// reciprocals above), 8 fewer instructions and 8 fewer links in the dependent chain per evaluation -- and getT runs 3.6
+// evaluations per layer-cell on the bench ensemble, all of them on the critical path of the up sweep.  Only taken where the
+// reference's clamps of S_br (1e-9 / 1e-10) are inactive (sb > 1e-4); 0 = two divisions.
+#ifndef SAMSIM_NEWTON1
+#define SAMSIM_NEWTON1 0
+#endif
+// one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1
+__device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
+  const double sb = S_br_poly(s, T_0);
+#if SAMSIM_NEWTON1 && SAMSIM_FAST_DIV
+  if (sb > 0.0001) {
+    const double sb2 = sb * sb, LS = latent_heat * S_bu;
+    const double A = -latent_heat - H + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
+    const double B = c_s + c_s_beta * T_0;
+    const double num = A * sb2 + LS * sb;
+    const double den = B * sb2 - LS * ddT_S_br(s, T_0);
+    T_new = T_0 - quot(num, den);
+    return fabs(num) > sb2;
+  }
+#endif
+  double f, ddT_f;
+  newton_terms(s, H, S_bu, T_0, sb, sb_floor, f, ddT_f);
+  T_new = T_0 - quot(f, ddT_f);
+  return fabs(f) > 1.0;
+}
+
 // H/c_l: the temperature of pure brine of enthalpy H (first line of getT, mo_thermo_functions.f90:84)
 __device__ __forceinline__ double T_liquid(double H) {
 #if SAMSIM_FAST_DIV
@@ -258,18 +369,16 @@ __device__ __forceinline__ double T_liquid(double H) {
 
 // getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
 // Returns 99 (the reference's STOP code) when 260 iterations do not converge.
-__device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out) {
+__device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out, int *evals = nullptr) {
   double T = T_liquid(H), phi = phi_out;
   int rc = 0;
   if (S_br_clamped(s, T, S_bu) > S_bu && S_bu > 0.001) {
-    double T_fr = 0.0, T_0, f, ddT_f, sb;
+    double T_fr = 0.0, T_0;
     bool have_T_fr = false;
     T_0 = T_in;
-    sb = S_br_poly(s, T_0);
-    newton_terms(s, H, S_bu, T_0, sb, 0.000000001, f, ddT_f);
-    T = T_0 - quot(f, ddT_f);
+    bool more = newton_step(s, H, S_bu, T_0, 0.000000001, T);
     int i = 0;
-    while (fabs(f) > 1.0) {
+    while (more) {
       T_0 = T;
       if (T_0 > 0.0 || T_0 < -200.0) {
         // The reference computes the freezing temperature T_fr up front (mo_thermo_functions.f90:85-92) and only reads it
@@ -284,9 +393,10 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
         }
         T_0 = T_fr;
       }
-      sb = S_br_poly(s, T_0);
-      newton_terms(s, H, S_bu, T_0, sb, 0.0000000001, f, ddT_f);
-      T = T_0 - quot(f, ddT_f);
+      more = newton_step(s, H, S_bu, T_0, 0.0000000001, T);
+#if SAMSIM_STAMPS == 2
+      if (evals) *evals += 1;
+#endif
       if (++i == 260) { rc = 99; break; }
     }
     phi = 1.0 - quot(S_bu, S_br_clamped(s, T, S_bu));
@@ -318,7 +428,19 @@ __device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_b
 // x**3.10 of the permeability law (mo_grav_drain.f90:105, mo_flush.f90:119,128, mo_flood.f90:73) as exp(3.1*log(x)):
 // within ~4e-15 relative of the correctly rounded pow() the reference links (|3.1*log x| <= 22 for x <= 1000), at a
 // third of its instructions and without the double-double constant tables that push the layer loops into spills.
+#ifndef SAMSIM_POW
+#define SAMSIM_POW 1
+#endif
+#if SAMSIM_POW
+}  // namespace
+#define SP_QUOT(a, b) quot(a, b)
+#include "samsim_pow.h"
+namespace {
+// x*x*x * exp(0.1*log(x)) with a plain logarithm: within ~4 ulp of the correctly rounded power (samsim_pow.h)
+__device__ __forceinline__ double pow_3p1(double x) { return sp_pow_3p1(x); }
+#else
 __device__ __forceinline__ double pow_3p1(double x) { return exp(3.10 * log(x)); }
+#endif
 
 // func_density, mo_functions.f90:51-62
 __device__ double func_density(double T, double S) {
@@ -387,12 +509,28 @@ struct Ctx {
   gdouble *bgc, *bgc_bot, *bfl, *out_bgc, *out_bgc_bot;
   int n_bgc;
   double bgc_total0;
+  // Which rows of the Rayleigh-number array the last up sweep wrote (bit k-1 of word (k-1)/64 = row k), per wave, in LDS.
+  // Gravity drainage only reads ray(k) where it exceeds ray_crit (mo_grav_drain.f90:144), which in winter holds in two or three
+  // of 80 layers: the up sweep stores a row only when some column of the wave is above the threshold in that layer (or when the
+  // whole array is wanted: output, end of a launch), the down sweeps load only those rows and take 0 elsewhere.
+  lu64 *rflag;
+  bool ray_rows_all;   // this up sweep stores every row
+#if SAMSIM_STAMPS
+  mutable Stamps st;
+#endif
 };
 #define BGC(t, k) (x.bgc + ((size_t)(t) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 #define BGC_BOT(t) (x.bgc_bot + (size_t)(t) * c.ncol)[c.col]
 #define BFL(r, k) (x.bfl + ((size_t)(r) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 // tracers exist only in the run-time-flag instantiation; in the fixed ones the test folds to false
 #define HAS_BGC (K::general && x.n_bgc > 0)
+
+// Does row k of the Rayleigh-number array hold this column's current value?  Row 1 is written by the first sweep of every step
+// (prologue_top_layer / sweep_thermo_expulsion), the other rows by the last up sweep where flagged (Ctx::rflag), and all of them by
+// this step's full first sweep.  A row that was not written held no value above ray_crit in any column of the wave.
+__device__ __forceinline__ bool ray_row_valid(const Col &c, const Ctx &x, int k) {
+  return k == 1 || c.ray_all || ((x.rflag[(k - 1) >> 6] >> ((k - 1) & 63)) & 1ull) != 0ull;
+}
 
 
 // ---------------------------------------------------------------- func_freeboard, mo_functions.f90:79-130
@@ -489,12 +627,12 @@ __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
 template <class K>
 __device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
-  if (!(dmax(c.liquid_precip, c.solid_precip) > 0.0)) return;
-  const double dt = g.dt, T2m = c.T2m;
+  if (!(dmax(CL(liquid_precip), CL(solid_precip)) > 0.0)) return;
+  const double dt = g.dt, T2m = CL(T2m);
   double solid, liquid;
-  if (CFG(precip_flag) == 0) { solid = c.solid_precip; liquid = c.liquid_precip; }
-  else if (T2m > 0.0) { solid = 0.0; liquid = c.liquid_precip; }
-  else { solid = c.liquid_precip; liquid = 0.0; }
+  if (CFG(precip_flag) == 0) { solid = CL(solid_precip); liquid = CL(liquid_precip); }
+  else if (T2m > 0.0) { solid = 0.0; liquid = CL(liquid_precip); }
+  else { solid = CL(liquid_precip); liquid = 0.0; }
   if (c.Na > 1) {
     double d_thick = dt * solid * rho_l / rho_snow;
     c.m_snow = c.m_snow + dt * rho_l * (liquid + solid);
@@ -655,7 +793,7 @@ __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m
 // writes the psi arrays itself, which is cheaper than handing psi_s, psi_l, psi_g and V_ex over through HBM.
 template <class K>
 __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bool do_ray, double T, double phi, double S_bu,
-                                         double m, double thick, RayScan &r) {
+                                         double m, double thick, RayScan &r, bool sparse_rows = false) {
   const samsim_config &g = x.p->cfg;
   const double S_br = S_br_clamped(x.salt, T, S_bu);
   const Expelled e = expulsion(phi, thick, m);
@@ -688,7 +826,12 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       ray = ray / (kappa_l * mu);
 #endif
       ray = dmax(ray, 0.0);
-      LAY(SAMSIM_A_RAY, k) = ray;
+      if (!sparse_rows) {
+        LAY(SAMSIM_A_RAY, k) = ray;
+      } else if (x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // the fused up sweep: wave-uniform k, see Ctx::rflag
+        LAY(SAMSIM_A_RAY, k) = ray;
+        if (wave_leader()) x.rflag[(k - 1) >> 6] |= 1ull << ((k - 1) & 63);
+      }
     }
   }
 }
@@ -738,12 +881,11 @@ template <class K>
 __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
-  const size_t nc = c.ncol;
   const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   RayScan r;
-  r.minp = c.spec[SP_MINP * nc]; r.stp = c.spec[SP_STP * nc]; r.st = c.spec[SP_ST * nc];
-  r.bot = c.spec[SP_BOT * nc]; r.botterm = c.spec[SP_BOTTERM * nc]; r.perm_bot = c.spec[SP_PERM_BOT * nc];
-  r.S_br_bot = c.spec[SP_SBR_BOT * nc]; r.buoy_s = c.spec[SP_BUOY_S * nc]; r.min_psi_s = c.spec[SP_MIN_PSI_S * nc];
+  r.minp = SPEC(SP_MINP); r.stp = SPEC(SP_STP); r.st = SPEC(SP_ST);
+  r.bot = SPEC(SP_BOT); r.botterm = SPEC(SP_BOTTERM); r.perm_bot = SPEC(SP_PERM_BOT);
+  r.S_br_bot = SPEC(SP_SBR_BOT); r.buoy_s = SPEC(SP_BUOY_S); r.min_psi_s = SPEC(SP_MIN_PSI_S);
   const double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1);
   double S_abs = LAY(SAMSIM_A_S_ABS, 1);
   if (S_abs < 0.0) { S_abs = 0.0; LAY(SAMSIM_A_S_ABS, 1) = S_abs; }
@@ -885,7 +1027,7 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   hp = hp + (thN * psN / psi_s_min) / permN;
   hp = (sth + thN * psN / psi_s_min) / hp;
   const double sall = sth + thN;
-  const double freeboard = c.freeboard, psi_g_snow = c.psi_g_snow;
+  const double freeboard = CL(freeboard), psi_g_snow = c.psi_g_snow;
   double flood_brine = -g.dt * grav_f * rho_l * rho_l * hp * (freeboard) / (mu * sall);
   const double shift_ice = flood_brine / (rho_l * psi_g_snow / ratio_flood);
   const double shift_snow = shift_ice * (1 + psi_g_snow / (1.0 - psi_g_snow) * (1.0 - 1.0 / ratio_flood));
@@ -933,7 +1075,7 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void flood_simple(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
-  const double shift = c.freeboard - neg_free;
+  const double shift = CL(freeboard) - neg_free;
   const double flood_brine = -shift * c.psi_g_snow * rho_l;
   double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
   th1 = th1 - shift;
@@ -1015,7 +1157,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     if (j <= Na - 1) {
       const double S_br = S_br_j;
       S_br_j = LAY(SAMSIM_A_S_BR, j + 1);
-      const double ray = LAY(SAMSIM_A_RAY, j);
+      const double ray = ray_row_valid(c, x, j) ? LAY(SAMSIM_A_RAY, j) : 0.0;
       if (ray > ray_crit && S_br > S_br_j) {
         const double psi_s = LAY(SAMSIM_A_PSI_S, j), m = LAY(SAMSIM_A_M, j);
         if (psi_s > 0.001 && r.S_abs / m > 0.1) {
@@ -1024,7 +1166,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
           flux = dmin(flux, psi_l * rho_l * thick);
           r.S_abs = r.S_abs - flux * S_br;
           if (r.S_abs < 0.0 && !stop_layer) stop_layer = j;
-          c.grav_temp = c.grav_temp + flux * r.T;
+          CL(grav_temp) = CL(grav_temp) + flux * r.T;
           r.H_abs = r.H_abs - flux * c_l * r.T;
           heat_loss = heat_loss + flux * c_l * r.T;
           cum = cum + flux;
@@ -1059,7 +1201,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
       cur.ch = true;
     }
     if (k == Na) {
-      c.grav_drain = c.grav_drain + cur.flup;
+      CL(grav_drain) = CL(grav_drain) + cur.flup;
       if (CFG(grav_heat_flag) == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
     }
     if (cur.ch) {
@@ -1071,8 +1213,8 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     flup_prev = cur.flup;
     cur = nxt;
   }
-  c.grav_salt = c.grav_salt + sum_before;
-  c.grav_salt = c.grav_salt - sum_after;
+  CL(grav_salt) = CL(grav_salt) + sum_before;
+  CL(grav_salt) = CL(grav_salt) - sum_after;
   if (stop_layer) STOPC(21234, stop_layer);
   if (minS < 0.0) STOPC(1337, 0);
 }
@@ -1080,7 +1222,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
 // fl_grav_drain_simple (mo_grav_drain.f90:218-278, grav_flag 3) with ray(k) from S1: every layer above the critical
 // Rayleigh number loses 1 % of its salt (`0.99` is a default-REAL literal); fused with the Beer-law pass like P3.
 template <class K>
-__device__ RARE void sweep_grav_drain_simple(Col &c, bool do_beer, double beer0) {
+__device__ RARE void sweep_grav_drain_simple(Col &c, const Ctx &x, bool do_beer, double beer0) {
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
   for (int k = 1; k <= Na; ++k) {
@@ -1090,9 +1232,9 @@ __device__ RARE void sweep_grav_drain_simple(Col &c, bool do_beer, double beer0)
       if (k == Na) c.frad = temp2 - temp2 * e;
       temp2 = temp2 * e;
     }
-    if (k <= Na - 1 && LAY(SAMSIM_A_RAY, k) > ray_crit) LAY(SAMSIM_A_S_ABS, k) = LAY(SAMSIM_A_S_ABS, k) * (double)0.99f;
+    if (k <= Na - 1 && ray_row_valid(c, x, k) && LAY(SAMSIM_A_RAY, k) > ray_crit) LAY(SAMSIM_A_S_ABS, k) = LAY(SAMSIM_A_S_ABS, k) * (double)0.99f;
   }
-  c.grav_drain = 0.0;
+  CL(grav_drain) = 0.0;
 }
 
 // Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
@@ -1134,6 +1276,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   // 4 waves/SIMD spills inside the loop: 93).
   struct Ld { double T, S_abs, m, H_abs, thick, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
+  unsigned long long rbits = x.rflag[0];   // row flags of rows 1..64; the next word is fetched when j crosses into it
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAY(SAMSIM_A_T, j);
@@ -1141,7 +1284,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     r.m = LAY(SAMSIM_A_M, j);
     r.H_abs = LAY(SAMSIM_A_H_ABS, j);
     r.thick = LAY(SAMSIM_A_THICK, j);
-    r.ray = (j <= Na - 1) ? LAY(SAMSIM_A_RAY, j) : 0.0;
+    if (((j - 1) & 63) == 0 && j > 1) rbits = x.rflag[(j - 1) >> 6];
+    r.ray = (j <= Na - 1 && (j == 1 || c.ray_all || ((rbits >> ((j - 1) & 63)) & 1ull) != 0ull)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
     return r;
   };
   auto finish = [&](const Ld &l) -> Raw {
@@ -1158,13 +1302,24 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   Ld ahead = load_ld(1);
   Raw raw = finish(ahead), raw_n = raw;
   if (Na >= 2) ahead = load_ld(2);
+#if SAMSIM_DAHEAD >= 3
+  Ld ahead2 = ahead;                                   // layer j+2 (ahead = layer j+1): requested two iterations before use
+  if (Na >= 3) ahead2 = load_ld(3);
+#endif
   Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
   const int jmax = wave_max(Na);
   for (int j = 1; j <= jmax; ++j) {
+    ISA_MARK("D_ITER_BEGIN");
     if (j > Na) continue;
+    ST_COUNT(CT_DOWN_TRIPS, 1);
     if (j < Na) raw_n = finish(ahead);
+#if SAMSIM_DAHEAD >= 3
+    ahead = ahead2;
+    if (j + 3 <= Na) ahead2 = load_ld(j + 3);
+#else
     if (j + 2 <= Na) ahead = load_ld(j + 2);
+#endif
     // ---- A(j)
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
@@ -1226,12 +1381,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       if (ray > ray_crit && S_br > raw_n.S_br) {
         const double psi_s = ex.psi_s;
         if (psi_s > 0.001 && S_bu > 0.1) {  // S_bu = S_abs/m of this layer, formed above (j < N_active: nothing changed since)
+          ST_COUNT(CT_DRAIN_WAVE, 1);
+          ST_COUNT(CT_DRAIN_LANE, (unsigned long long)__popcll(__ballot(1)));
           const double psi_l = ex.psi_l;
           double flux = x_grav * (ray - ray_crit) * dt * thick;
           flux = dmin(flux, psi_l * rho_l * thick);
           S_abs = S_abs - flux * S_br;
           if (S_abs < 0.0 && !stop_layer) stop_layer = j;
-          c.grav_temp = c.grav_temp + flux * T;
+          CL(grav_temp) = CL(grav_temp) + flux * T;
           H_abs = H_abs - flux * c_l * T;
           heat_loss = heat_loss + flux * c_l * T;
           cum = cum + flux;
@@ -1258,6 +1415,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     }
     prev.T = T; prev.S_bu = S_bu; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
     raw = raw_n;
+    ISA_MARK("D_ITER_END");
   }
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
@@ -1268,15 +1426,15 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
     prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
   }
-  c.grav_drain = c.grav_drain + prev.flup;
+  CL(grav_drain) = CL(grav_drain) + prev.flup;
   if (CFG(grav_heat_flag) == 2) prev.H_abs = prev.H_abs + heat_loss - prev.flup * c_l * g.T_bottom;
   LAY(SAMSIM_A_M, Na) = prev.m;
   LAY(SAMSIM_A_S_ABS, Na) = prev.S_abs;
   LAY(SAMSIM_A_H_ABS, Na) = prev.H_abs;
   minS = dmin(minS, prev.S_abs);
   c.buoy_g = buoy_g;
-  c.grav_salt = c.grav_salt + sum_before;
-  c.grav_salt = c.grav_salt - sum_after;
+  CL(grav_salt) = CL(grav_salt) + sum_before;
+  CL(grav_salt) = CL(grav_salt) - sum_after;
   if (stop_layer) STOPC(21234, stop_layer);
   if (minS < 0.0) STOPC(1337, 0);
 }
@@ -1289,15 +1447,15 @@ template <class K>
 __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (CFG(boundflux_flag) != 2) return 0.0;
-  c.albedo = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, CFG(albedo_flag));
+  CL(albedo) = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, CFG(albedo_flag));
   if (!K::general || CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
-      c.fl_sw = x.f_sw[x.soff + tc - 1];
-      c.fl_lw = x.f_lw[x.soff + tc - 1];
+      CL(fl_sw) = x.f_sw[x.soff + tc - 1];
+      CL(fl_lw) = x.f_lw[x.soff + tc - 1];
     } else {
       const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-      c.fl_sw = (1.0 - temp) * x.f_sw[x.soff + tc - 2] + temp * x.f_sw[x.soff + tc - 1];
-      c.fl_lw = (1.0 - temp) * x.f_lw[x.soff + tc - 2] + temp * x.f_lw[x.soff + tc - 1];
+      CL(fl_sw) = (1.0 - temp) * x.f_sw[x.soff + tc - 2] + temp * x.f_sw[x.soff + tc - 1];
+      CL(fl_lw) = (1.0 - temp) * x.f_lw[x.soff + tc - 2] + temp * x.f_lw[x.soff + tc - 1];
     }
   } else if (CFG(atmoflux_flag) == 1) {
     // sub_notzflux(time + 180 days), mo_functions.f90:270-289 (47.9, 53.1 are default-REAL literals); fl_rest lives in
@@ -1305,12 +1463,12 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
     double day = (time + 86400.0 * 180.0) / 86400.0;
     while (day > 360.0) day = day - 360.0;
     const double a = (day - 164.0) / (double)47.9f, b = (day - 206.0) / (double)53.1f;
-    c.fl_sw = 314.0 * exp(-0.5 * (a * a));
-    if (day < 60.0 || day > 300.0) c.fl_sw = 0.0;
+    CL(fl_sw) = 314.0 * exp(-0.5 * (a * a));
+    if (day < 60.0 || day > 300.0) CL(fl_sw) = 0.0;
     x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col] = 118.0 * exp(-0.5 * (b * b)) + 179.0;
   }
   const double pen = (c.thick_snow < g.thick_min) ? penetr : 0.0;
-  return pen * (1.0 - c.albedo) * c.fl_sw;
+  return pen * (1.0 - CL(albedo)) * CL(fl_sw);
 }
 
 // twice-iterated linearised radiative balance for the surface temperature, mo_heat_fluxes.f90:115-148: a function of the
@@ -1320,12 +1478,12 @@ __device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, 
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
   T_old = T_old + zeroK;
-  double temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  double temp1 = (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) + fl_rest;
   temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
   temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
   temp1 = temp1 - zeroK;
   T_old = temp1 + zeroK;
-  temp1 = (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw + fl_rest;
+  temp1 = (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) + fl_rest;
   temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
   temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
   temp1 = temp1 - zeroK;
@@ -1346,35 +1504,35 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
     return;
   }
   if (K::general && CFG(boundflux_flag) == 3) {  // lab air temperature, mo_heat_fluxes.f90:202-219 (lab_snow_flag 0)
-    c.T_freeze = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
+    CL(T_freeze) = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
     c.T_top = T1;
-    c.fl_Q1 = g.alpha_flux_instable * (c.T_top - c.T2m);
+    c.fl_Q1 = g.alpha_flux_instable * (c.T_top - CL(T2m));
     if (c.fl_Q1 < 0.0) {
-      c.T_top = dmax(c.T_freeze, T1);
-      c.fl_Q1 = g.alpha_flux_stable * (c.T_top - c.T2m);
+      c.T_top = dmax(CL(T_freeze), T1);
+      c.fl_Q1 = g.alpha_flux_stable * (c.T_top - CL(T2m));
     }
     return;
   }
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
-  const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? c.fl_lw + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
+  const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? CL(fl_lw) + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
   double temp1;
   c.T_top = radiative_T_top(c, fl_rest, T1, thick_min);
 
-  if (c.thick_snow >= thick_min / 100.0) c.T_freeze = 0.0;
-  else c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+  if (c.thick_snow >= thick_min / 100.0) CL(T_freeze) = 0.0;
+  else CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
 
   const double k_snow = (c.thick_snow >= thick_min / 100.0) ? func_k_snow(c.m_snow, c.thick_snow) : 0.0;
   // sub_fl_Q_snow, mo_snow.f90:498-518
   const double flq_snow_ice = (T1 - c.T_snow) / (c.thick_snow / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
-  if (c.T_top > c.T_freeze && Na > 1) {
-    temp1 = emi * sigma * pow(c.T_freeze + zeroK, 4.0) - (1.0 - c.albedo) * (1.0 - pen) * c.fl_sw - fl_rest;
+  if (c.T_top > CL(T_freeze) && Na > 1) {
+    temp1 = emi * sigma * pow(CL(T_freeze) + zeroK, 4.0) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
     if (c.thick_snow >= thick_min) { c.fl_Q_snow = temp1; c.fl_Q1 = flq_snow_ice; }
     else if (c.thick_snow >= thick_min / 100.0) { c.fl_Q_snow = temp1; c.fl_Q1 = 0.0; }
     else c.fl_Q1 = temp1;
-    c.T_top = c.T_freeze;
+    c.T_top = CL(T_freeze);
   } else {
     if (c.thick_snow >= thick_min) {
       c.fl_Q1 = flq_snow_ice;
@@ -1403,7 +1561,6 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
-  const size_t nc = c.ncol;
   const double dt = g.dt, thick_min = g.thick_min;
   const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
   const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
@@ -1419,28 +1576,36 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
     for (int k = 1; k <= c.N - 1; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * c.N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
   }
-  if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
-  // layer k (old values)
-  double T_k = LAY(SAMSIM_A_T, Na), th_k = LAY(SAMSIM_A_THICK, Na);
-  // half resistance thick/(2k) of layer k, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp, mo_thermo_functions.f90:213:
+  for (int w = 0; w <= (c.N - 1) >> 6; ++w) x.rflag[w] = 0ull;   // every lane writes the same zeros
+  if (do_ray && Na <= c.N - 1 && x.ray_rows_all) LAY(SAMSIM_A_RAY, Na) = 0.0;   // (read by `output` only)
+  // half resistance thick/(2k) of a layer, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp, mo_thermo_functions.f90:213:
   // a no-op for finite psi_g): the same quotient serves fl_Q(k+1) and fl_Q(k).  Layers >= 2 take it from the down sweep;
   // layer 1 forms it here, because flooding and snow-ice formation change thick(1) between the two sweeps.
   const double hr_top = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
-  double hr_k = (Na >= 2) ? LAY(D_HR, Na) : hr_top;
-  // H_abs, m, S_abs of layer k are loaded one iteration ahead, together with T, thick and the half resistance of layer k-1
-  // that the stencil needs now: a whole iteration of arithmetic hides their latency
-  double H_k = LAY(SAMSIM_A_H_ABS, Na), m_k = LAY(SAMSIM_A_M, Na), S_k = LAY(SAMSIM_A_S_ABS, Na);
+  // The six values of a layer -- old T, thick, half resistance, H_abs, m, S_abs -- are requested TWO iterations before the
+  // layer's own iteration: the stencil of iteration k reads T and the half resistance of layer k-1 at once, so a request made at
+  // the top of iteration k (as it was up to round 1 for these two) exposes the full HBM latency in every iteration; made at the
+  // top of iteration k+1 it has a whole iteration of arithmetic (a Newton chain of ~3.6 evaluations) to arrive.
+  struct UL { double T, th, hr, H, m, S; };
+  auto load_ul = [&](int j) -> UL {
+    UL r;
+    r.T = LAY(SAMSIM_A_T, j); r.th = LAY(SAMSIM_A_THICK, j);
+    r.hr = (j >= 2) ? LAY(D_HR, j) : hr_top;
+    r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.S = LAY(SAMSIM_A_S_ABS, j);
+    return r;
+  };
+  UL cur = load_ul(Na), nxt = cur, nn = cur;   // layers k, k-1, k-2
+  if (Na >= 2) nxt = load_ul(Na - 1);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
+    ISA_MARK("U_ITER_BEGIN");
     if (k > Na) continue;
-    double flq_k, T_u = 0.0, th_u = 0.0, hr_u = 0.0, H_u = 0.0, m_u = 0.0, S_u = 0.0;
+    if (k >= 3) nn = load_ul(k - 2);
+    double flq_k;
+    const double T_k = cur.T, th_k = cur.th, hr_k = cur.hr, H_k = cur.H, m_k = cur.m, S_k = cur.S;
     if (k > 1) {
-      T_u = LAY(SAMSIM_A_T, k - 1);
-      th_u = LAY(SAMSIM_A_THICK, k - 1);
-      hr_u = (k > 2) ? LAY(D_HR, k - 1) : hr_top;
-      H_u = LAY(SAMSIM_A_H_ABS, k - 1); m_u = LAY(SAMSIM_A_M, k - 1); S_u = LAY(SAMSIM_A_S_ABS, k - 1);
-      const double R = hr_u + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
-      flq_k = quot(T_k - T_u, R);
+      const double R = nxt.hr + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
+      flq_k = quot(T_k - nxt.T, R);
     } else {
       flq_k = c.fl_Q1;
     }
@@ -1466,7 +1631,18 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     double S_bu, H;
     per_mass(S_abs, H_abs, m, S_bu, H);
     double T, phi = 0.0;
+    ISA_MARK("U_GETT_BEGIN");
+#if SAMSIM_STAMPS == 2
+    int evals = 1;
+    int rr = getT(s, H, S_bu, T_test, T, phi, &evals);
+    ST_COUNT(CT_UP_TRIPS, 1);
+    ST_COUNT(CT_NEWTON_WAVE, (unsigned long long)wave_max(evals));
+    { int tot = 0; unsigned long long mk = __ballot(1); while (mk) { const int ln = __ffsll((long long)mk) - 1; tot += __builtin_amdgcn_readlane(evals, ln); mk &= mk - 1; }
+      ST_COUNT(CT_NEWTON_LANE, (unsigned long long)tot); }
+#else
     int rr = getT(s, H, S_bu, T_test, T, phi);
+#endif
+    ISA_MARK("U_GETT_END");
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
     LAY(SAMSIM_A_T, k) = T;
@@ -1480,15 +1656,16 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r);
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r, true);
     }
     flq_below = flq_k;
-    T_k = T_u; th_k = th_u; hr_k = hr_u; H_k = H_u; m_k = m_u; S_k = S_u;
+    cur = nxt; nxt = nn;
+    ISA_MARK("U_ITER_END");
   }
   // hand-over block for prologue_top_layer of the next step
-  c.spec[SP_MINP * nc] = r.minp; c.spec[SP_STP * nc] = r.stp; c.spec[SP_ST * nc] = r.st;
-  c.spec[SP_BOT * nc] = r.bot; c.spec[SP_BOTTERM * nc] = r.botterm; c.spec[SP_PERM_BOT * nc] = r.perm_bot;
-  c.spec[SP_SBR_BOT * nc] = r.S_br_bot; c.spec[SP_BUOY_S * nc] = r.buoy_s; c.spec[SP_MIN_PSI_S * nc] = r.min_psi_s;
+  SPEC(SP_MINP) = r.minp; SPEC(SP_STP) = r.stp; SPEC(SP_ST) = r.st;
+  SPEC(SP_BOT) = r.bot; SPEC(SP_BOTTERM) = r.botterm; SPEC(SP_PERM_BOT) = r.perm_bot;
+  SPEC(SP_SBR_BOT) = r.S_br_bot; SPEC(SP_BUOY_S) = r.buoy_s; SPEC(SP_MIN_PSI_S) = r.min_psi_s;
   // energy conservation assert, mo_heat_fluxes.f90:265-310
   double temp1 = sum_before + H_abs_snow_before;
   temp1 = temp1 + (double)Na * (c.frad * dt);
@@ -1559,9 +1736,9 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     R_below = R;
   }
   const double R1 = R_below;
-  double flush_total = (c.freeboard + c.melt_thick) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
+  double flush_total = (CL(freeboard) + c.melt_thick) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
   flush_total = dmin(flush_total, c.melt_thick * rho_l);
-  c.melt_err = c.melt_err + c.melt_thick - dmin(flush_total / rho_l, c.melt_thick);
+  CL(melt_err) = CL(melt_err) + c.melt_thick - dmin(flush_total / rho_l, c.melt_thick);
 
   // top -> bottom: split into vertical / horizontal parts, vertical mass_transfer (fl_m(k+1) = -flush_v(k) <= 0),
   // horizontal loss of every layer goes to layer N_active
@@ -1916,14 +2093,14 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   } else if (phi_N > psi_s_min && bf == 1) {
     for (int tr = nt - 1; tr >= -1; --tr) bottom_growth<K>(c, x, tr);
   } else if (th1 > 1.5 * thick_0) {
-    c.melt_out3 = c.melt_out3 - th1;
+    CL(melt_out3) = CL(melt_out3) - th1;
     for (int tr = nt - 1; tr >= -1; --tr) top_grow<K>(c, x, tr);
-    c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
+    CL(melt_out3) = CL(melt_out3) + LAY(SAMSIM_A_THICK, 1);
   } else if (th1 < 0.5 * thick_0) {
-    c.melt_out3 = c.melt_out3 - th1;
+    CL(melt_out3) = CL(melt_out3) - th1;
     for (int tr = nt - 1; tr >= -1; --tr) top_melt<K>(c, x, tr);
     if (c.status) return;
-    c.melt_out3 = c.melt_out3 + LAY(SAMSIM_A_THICK, 1);
+    CL(melt_out3) = CL(melt_out3) + LAY(SAMSIM_A_THICK, 1);
   }
 }
 
@@ -1932,11 +2109,18 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double time) {
   const samsim_config &g = x.p->cfg;
-  if (c.Na > 1) c.freeboard = func_freeboard<K>(c, x); else c.freeboard = 0.0;
+  if (c.Na > 1) CL(freeboard) = func_freeboard<K>(c, x); else CL(freeboard) = 0.0;
   if (CFG(grav_flag) == 2) {
-    if (c.grav_drain == 0.0) c.grav_temp = 0.0; else c.grav_temp = c.grav_temp / c.grav_drain;
-    c.grav_salt = c.grav_salt / g.time_out;
-    c.grav_drain = c.grav_drain / g.time_out;
+    if (CL(grav_drain) == 0.0) CL(grav_temp) = 0.0; else CL(grav_temp) = CL(grav_temp) / CL(grav_drain);
+    CL(grav_salt) = CL(grav_salt) / g.time_out;
+    CL(grav_drain) = CL(grav_drain) / g.time_out;
+  }
+  {  // the vital signs are not carried in registers between output points: their slots of the scalar block are written here
+    gdouble *sc = x.scal + c.col;
+    const size_t nc = c.ncol;
+    sc[(size_t)SAMSIM_S_ENERGY_STORED * nc] = c.energy_stored; sc[(size_t)SAMSIM_S_FRESHWATER * nc] = c.freshwater;
+    sc[(size_t)SAMSIM_S_TOTAL_RESIST * nc] = c.total_resist; sc[(size_t)SAMSIM_S_THICKNESS * nc] = c.thickness;
+    sc[(size_t)SAMSIM_S_BULK_SALIN * nc] = c.bulk_salin;
   }
   if (col >= x.out_col0 && col < x.out_col0 + x.out_ncols) {
     const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
@@ -1953,19 +2137,19 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
     OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
     OUT(SAMSIM_S_PSI_G_SNOW, c.psi_g_snow); OUT(SAMSIM_S_T_SNOW, c.T_snow); OUT(SAMSIM_S_PHI_S, c.phi_s);
-    OUT(SAMSIM_S_T_TOP, c.T_top); OUT(SAMSIM_S_MELT_THICK, c.melt_thick); OUT(SAMSIM_S_T2M, c.T2m);
-    OUT(SAMSIM_S_LIQUID_PRECIP, c.liquid_precip); OUT(SAMSIM_S_SOLID_PRECIP, c.solid_precip); OUT(SAMSIM_S_FL_Q_BOTTOM, c.fl_q_bottom);
-    OUT(SAMSIM_S_GRAV_DRAIN, c.grav_drain); OUT(SAMSIM_S_GRAV_SALT, c.grav_salt); OUT(SAMSIM_S_GRAV_TEMP, c.grav_temp);
-    OUT(SAMSIM_S_MELT_OUT1, c.melt_out1); OUT(SAMSIM_S_MELT_OUT2, c.melt_out2); OUT(SAMSIM_S_MELT_OUT3, c.melt_out3);
-    OUT(SAMSIM_S_MELT_ERR, c.melt_err); OUT(SAMSIM_S_FREEBOARD, c.freeboard); OUT(SAMSIM_S_T_FREEZE, c.T_freeze);
-    OUT(SAMSIM_S_ALBEDO, c.albedo); OUT(SAMSIM_S_FL_SW, c.fl_sw); OUT(SAMSIM_S_FL_LW, c.fl_lw);
+    OUT(SAMSIM_S_T_TOP, c.T_top); OUT(SAMSIM_S_MELT_THICK, c.melt_thick); OUT(SAMSIM_S_T2M, CL(T2m));
+    OUT(SAMSIM_S_LIQUID_PRECIP, CL(liquid_precip)); OUT(SAMSIM_S_SOLID_PRECIP, CL(solid_precip)); OUT(SAMSIM_S_FL_Q_BOTTOM, c.fl_q_bottom);
+    OUT(SAMSIM_S_GRAV_DRAIN, CL(grav_drain)); OUT(SAMSIM_S_GRAV_SALT, CL(grav_salt)); OUT(SAMSIM_S_GRAV_TEMP, CL(grav_temp));
+    OUT(SAMSIM_S_MELT_OUT1, CL(melt_out1)); OUT(SAMSIM_S_MELT_OUT2, CL(melt_out2)); OUT(SAMSIM_S_MELT_OUT3, CL(melt_out3));
+    OUT(SAMSIM_S_MELT_ERR, CL(melt_err)); OUT(SAMSIM_S_FREEBOARD, CL(freeboard)); OUT(SAMSIM_S_T_FREEZE, CL(T_freeze));
+    OUT(SAMSIM_S_ALBEDO, CL(albedo)); OUT(SAMSIM_S_FL_SW, CL(fl_sw)); OUT(SAMSIM_S_FL_LW, CL(fl_lw));
     OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
-    OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? c.fl_lw + 0.0 + 0.0
+    OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? CL(fl_lw) + 0.0 + 0.0
                                                                         : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
     OUT(SAMSIM_S_S_BU_BOTTOM, x.S_bu_bottom);
-    OUT(SAMSIM_S_DT2M, c.dT2m); OUT(SAMSIM_S_PRECIP_SCALE, c.precip_scale);
+    OUT(SAMSIM_S_DT2M, CL(dT2m)); OUT(SAMSIM_S_PRECIP_SCALE, CL(precip_scale));
 #undef OUT
     x.out_n_active[oc] = c.Na;
     if (HAS_BGC) {
@@ -1975,8 +2159,8 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
       }
     }
   }
-  c.grav_drain = 0.0; c.grav_salt = 0.0; c.grav_temp = 0.0;
-  c.melt_out1 = 0.0; c.melt_out2 = 0.0; c.melt_out3 = 0.0;
+  CL(grav_drain) = 0.0; CL(grav_salt) = 0.0; CL(grav_temp) = 0.0;
+  CL(melt_out1) = 0.0; CL(melt_out2) = 0.0; CL(melt_out3) = 0.0;
   (void)time;
 }
 
@@ -2048,26 +2232,26 @@ __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g,
       if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
     }
   } else if (K::general && CFG(testcase) == 3) {  // sub_test3, :172-187
-    c.liquid_precip = 0.0;
-    c.solid_precip = 0.15 / 86400.0 / 356.0;
+    CL(liquid_precip) = 0.0;
+    CL(solid_precip) = 0.15 / 86400.0 / 356.0;
   } else if (CFG(testcase) == 4 || CFG(testcase) == 7) {  // sub_test4, :197-202
     c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
   } else if (K::general && CFG(testcase) == 2) {  // sub_test2, :99-111
-    if (time > 86400.0 * 25.0) c.T2m = 15.0;
-    else if (time > 86400.0 * 15.0) c.T2m = 1.0;
+    if (time > 86400.0 * 25.0) CL(T2m) = 15.0;
+    else if (time > 86400.0 * 15.0) CL(T2m) = 1.0;
   } else if (K::general && CFG(testcase) == 9) {  // sub_test9, :121-136
-    if (time < 19.75 * 3600.0) c.T2m = 0.0;
-    else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) c.T2m = -15.0;
-    else c.T2m = 1.0;
+    if (time < 19.75 * 3600.0) CL(T2m) = 0.0;
+    else if (time < 86400.0 * 3.0 + 2.25 * 3600.0) CL(T2m) = -15.0;
+    else CL(T2m) = 1.0;
   } else if (K::general && CFG(testcase) == 34) {  // sub_test34, :146-162
-    if (time < 2.0 * 3600.0) c.T2m = 0.0;
-    else if (time < 86400.0 * 5.0) c.T2m = -15.0;
-    else if (time < 86400.0 * 7.0) c.T2m = -5.0;
-    else c.T2m = 1.0;
+    if (time < 2.0 * 3600.0) CL(T2m) = 0.0;
+    else if (time < 86400.0 * 5.0) CL(T2m) = -15.0;
+    else if (time < 86400.0 * 7.0) CL(T2m) = -5.0;
+    else CL(T2m) = 1.0;
   } else if (K::general && CFG(testcase) == 6) {  // sub_test6, :211-232
     const double t[8] = {1714.0, 1676.0, 1525.0, 1483.0, 1385.0, 1349.0, 1160.0, 1100.0};
     for (int i = 0; i < 8; ++i) {
-      if (time > t[i] * 60.0) { c.T2m = (i == 0) ? -19.0 : ((i & 1) ? -5.0 : -18.0); break; }
+      if (time > t[i] * 60.0) { CL(T2m) = (i == 0) ? -19.0 : ((i & 1) ? -5.0 : -18.0); break; }
     }
   }
 }
@@ -2105,11 +2289,11 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
       // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
       const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
       if (c.m_snow > buoy) {
-        c.freeboard = (buoy - c.m_snow) / rho_l;
-        if (c.freeboard < 0.0 && CFG(flood_flag) == 2) {
+        CL(freeboard) = (buoy - c.m_snow) / rho_l;
+        if (CL(freeboard) < 0.0 && CFG(flood_flag) == 2) {
           flood<K>(c, x);
           if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
-        } else if (K::general && CFG(flood_flag) == 3 && c.freeboard < neg_free) {
+        } else if (K::general && CFG(flood_flag) == 3 && CL(freeboard) < neg_free) {
           flood_simple<K>(c, x);
           if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
         }
@@ -2138,7 +2322,7 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
       c.bgc_grav = true;
       if (c.status) return;
     } else if (K::general && CFG(grav_flag) == 3 && Na > 1) {
-      sweep_grav_drain_simple<K>(c, do_beer, beer0);
+      sweep_grav_drain_simple<K>(c, x, do_beer, beer0);
     } else if (do_beer) {
       sweep_beer<K>(c, beer0);
     }
@@ -2168,15 +2352,15 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // forcing, mo_grotz.f90:229-241 (+ ensemble perturbation)
   if (CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
-      c.T2m = x.f_T2m[x.soff + tc - 1];
-      c.liquid_precip = x.f_precip[x.soff + tc - 1];
+      CL(T2m) = x.f_T2m[x.soff + tc - 1];
+      CL(liquid_precip) = x.f_precip[x.soff + tc - 1];
     } else {
       const double temp = (time - time_input(tc - 1)) / (time_input(tc) - time_input(tc - 1));
-      c.T2m = (1.0 - temp) * x.f_T2m[x.soff + tc - 2] + temp * x.f_T2m[x.soff + tc - 1];
-      c.liquid_precip = (1.0 - temp) * x.f_precip[x.soff + tc - 2] + temp * x.f_precip[x.soff + tc - 1];
+      CL(T2m) = (1.0 - temp) * x.f_T2m[x.soff + tc - 2] + temp * x.f_T2m[x.soff + tc - 1];
+      CL(liquid_precip) = (1.0 - temp) * x.f_precip[x.soff + tc - 2] + temp * x.f_precip[x.soff + tc - 1];
     }
-    c.T2m = c.T2m + c.dT2m;
-    c.liquid_precip = c.liquid_precip * c.precip_scale;
+    CL(T2m) = CL(T2m) + CL(dT2m);
+    CL(liquid_precip) = CL(liquid_precip) * CL(precip_scale);
   }
 
   c.bgc_flood = 0.0; c.bgc_grav = false;
@@ -2186,7 +2370,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 
   // first thermodynamic sweep, mo_grotz.f90:297-307 (+ Rayleigh numbers): only layer 1 is left to do unless the
   // column changed below layer 1 since the last up sweep
-  if (c.flags & COLF_DIRTY) sweep_thermo_expulsion<K>(c, x);
+  c.ray_all = (c.flags & COLF_DIRTY) != 0;
+  if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); sweep_thermo_expulsion<K>(c, x); }
   else prologue_top_layer<K>(c, x);
   c.flags = 0;
   if (c.status) return;
@@ -2203,7 +2388,11 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2);
 
+  ST_MARK(ST_PRO);
+  ST_COUNT(CT_WAVESTEPS, 1);
+  ST_COUNT(CT_LANES, (unsigned long long)__popcll(__ballot(1)));
   if (fused) {
+    ST_COUNT(CT_FUSED, 1);
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
     testcase_scalars<K>(c, g, time);
@@ -2220,7 +2409,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       const double th1 = LAY(SAMSIM_A_THICK, 1), m1 = LAY(SAMSIM_A_M, 1);
       const Expelled e1 = expulsion(LAY(SAMSIM_A_PHI, 1), th1, m1);
       const double T_fr = (c.thick_snow >= g.thick_min / 100.0) ? 0.0 : func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / m1, CFG(salt_flag), x.tf_c3);
-      const double T_top_est = radiative_T_top(c, c.fl_lw + 0.0 + 0.0, LAY(SAMSIM_A_T, 1), g.thick_min);
+      const double T_top_est = radiative_T_top(c, CL(fl_lw) + 0.0 + 0.0, LAY(SAMSIM_A_T, 1), g.thick_min);
       store_psi = next_out || last_step || e1.psi_s < psi_s_top_min + 0.05 || T_top_est >= T_fr - 1.0 ||
                   (c.thick_snow > 0.0 && (c.T_snow > -8.0 || c.melt_thick_snow > 0.0));
     }
@@ -2228,10 +2417,13 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     if (K::fixed && K::flush_flag == 1) store_psi = next_out || last_step;
     c.psi_full = store_psi;
     sweep_down_fused<K>(c, x, do_beer, beer0, store_psi);
+    ST_MARK(ST_DFUSED);
     if (c.status) return;
   } else {
+    ST_COUNT(CT_UNFUSED, 1);
     c.psi_full = true;
     down_unfused<K>(c, x, col, time, tc, out_step, coupling, do_grav, do_beer);
+    ST_MARK(ST_DUNFUSED);
     if (c.status) return;
   }
 
@@ -2250,7 +2442,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
   surface_flux<K>(c, x);
+  ST_MARK(ST_SURF);
   sweep_up_fused<K>(c, x, col, next_out, next_out || last_step);
+  ST_MARK(ST_UP);
   if (c.status) return;
 
   // snow thermodynamics again, mo_grotz.f90:603-625
@@ -2264,19 +2458,19 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   if (Na > 1 && CFG(flush_flag) > 2 && (CFG(boundflux_flag) == 2 || (K::general && CFG(boundflux_flag) == 3))) {
     // boundflux_flag 3 (:649-663) runs the same block on the air temperature instead of the surface temperature
     const bool lab = K::general && CFG(boundflux_flag) == 3;
-    const double T_surf = lab ? c.T2m : c.T_top;
-    c.T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+    const double T_surf = lab ? CL(T2m) : c.T_top;
+    CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
     c.melt_thick = 0.0;
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
-    if (psi_s1 < psi_s_top_min || T_surf >= c.T_freeze) {
+    if (psi_s1 < psi_s_top_min || T_surf >= CL(T_freeze)) {
       if (!c.psi_full) STOPC(9001, 0);
-      c.freeboard = func_freeboard<K>(c, x);
+      CL(freeboard) = func_freeboard<K>(c, x);
       fb_valid = true;
-      if (c.freeboard > 0.0000000000001) {
+      if (CL(freeboard) > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
-        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), c.T_freeze, T_surf, c.fl_Q1,
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), CL(T_freeze), T_surf, c.fl_Q1,
                        c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
         if (lab) c.melt_thick = dmax(c.melt_thick, 0.0);
         if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
@@ -2312,9 +2506,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
                                c.melt_thick + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !c.psi_full) STOPC(9001, 0);
-  if (flush_possible && !fb_valid) c.freeboard = func_freeboard<K>(c, x);
-  c.melt_out1 = c.melt_out1 + c.melt_thick;
-  c.melt_out2 = c.melt_out2 + c.melt_thick_snow;
+  if (flush_possible && !fb_valid) CL(freeboard) = func_freeboard<K>(c, x);
+  CL(melt_out1) = CL(melt_out1) + c.melt_thick;
+  CL(melt_out2) = CL(melt_out2) + c.melt_thick_snow;
   c.melt_thick = c.melt_thick + c.melt_thick_snow;
   if (c.melt_thick_snow > 0.0) {
     const double mts = c.melt_thick_snow;
@@ -2326,7 +2520,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + mts;
     LAY(SAMSIM_A_S_BU, 1) = S1 / m1;
   }
-  if (flush_possible && c.freeboard > 0.001) {
+  if (flush_possible && CL(freeboard) > 0.001) {
     if (c.melt_thick > 0.000000000001) {
       if (K::general && CFG(flush_flag) == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
         const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
@@ -2341,7 +2535,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
           if (c.status) return;
         }
       } else {
-        if (c.melt_thick_snow > 0.0) c.freeboard = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
+        if (c.melt_thick_snow > 0.0) CL(freeboard) = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
         flush3<K>(c, x);
         c.flags |= COLF_DIRTY;
         if (c.status) return;
@@ -2378,6 +2572,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     }
   }
 
+  ST_MARK(ST_POST);
   // health check, mo_grotz.f90:808-819 (negative S_abs is clamped element-wise at the next sweep)
   if (c.min_psi_s < 0.0) STOPC(1337, 0);
   if (c.Na == 1) {
@@ -2419,9 +2614,19 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   if ((K::fixed ? K::salt_flag : p.cfg.salt_flag) == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
+#if SAMSIM_STAMPS
+  __shared__ unsigned long long st_lds[32];
+  if (threadIdx.x < 32) st_lds[threadIdx.x] = 0;
+  __syncthreads();
+  x.st.acc = st_lds;
+  x.st.t0 = __builtin_amdgcn_s_memtime();
+#endif
   Col c;
   c.lay = (gdouble *)lay;
   c.col = (unsigned)col;
+  c.coff = (unsigned)col * 8u;
+  c.rstride = (unsigned)p.ncol * 8u;
+  c.astride = (size_t)p.cfg.nlayer * (size_t)p.ncol * 8u;
   c.ncol = (size_t)p.ncol;
   c.N = p.cfg.nlayer;
   c.Na = n_active[col];
@@ -2430,24 +2635,32 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.err_step = err_step[col];
   c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
-  c.spec = (gdouble *)spec + col;
+  c.spec = (gdouble *)spec;
   const size_t nc = (size_t)p.ncol;
   double *sc = scal + col;
 #define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
   SLOAD(m_snow, SAMSIM_S_M_SNOW); SLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SLOAD(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SLOAD(thick_snow, SAMSIM_S_THICK_SNOW); SLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SLOAD(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
   SLOAD(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SLOAD(T_snow, SAMSIM_S_T_SNOW); SLOAD(phi_s, SAMSIM_S_PHI_S);
-  SLOAD(T_top, SAMSIM_S_T_TOP); SLOAD(melt_thick, SAMSIM_S_MELT_THICK); SLOAD(T2m, SAMSIM_S_T2M);
-  SLOAD(liquid_precip, SAMSIM_S_LIQUID_PRECIP); SLOAD(solid_precip, SAMSIM_S_SOLID_PRECIP); SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
-  SLOAD(grav_drain, SAMSIM_S_GRAV_DRAIN); SLOAD(grav_salt, SAMSIM_S_GRAV_SALT); SLOAD(grav_temp, SAMSIM_S_GRAV_TEMP);
-  SLOAD(melt_out1, SAMSIM_S_MELT_OUT1); SLOAD(melt_out2, SAMSIM_S_MELT_OUT2); SLOAD(melt_out3, SAMSIM_S_MELT_OUT3);
-  SLOAD(melt_err, SAMSIM_S_MELT_ERR); SLOAD(freeboard, SAMSIM_S_FREEBOARD); SLOAD(T_freeze, SAMSIM_S_T_FREEZE);
-  SLOAD(albedo, SAMSIM_S_ALBEDO); SLOAD(fl_sw, SAMSIM_S_FL_SW); SLOAD(fl_lw, SAMSIM_S_FL_LW);
+  SLOAD(T_top, SAMSIM_S_T_TOP); SLOAD(melt_thick, SAMSIM_S_MELT_THICK); SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
   SLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SLOAD(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
-  SLOAD(energy_stored, SAMSIM_S_ENERGY_STORED); SLOAD(freshwater, SAMSIM_S_FRESHWATER); SLOAD(total_resist, SAMSIM_S_TOTAL_RESIST);
-  SLOAD(thickness, SAMSIM_S_THICKNESS); SLOAD(bulk_salin, SAMSIM_S_BULK_SALIN);
-  SLOAD(dT2m, SAMSIM_S_DT2M); SLOAD(precip_scale, SAMSIM_S_PRECIP_SCALE);
 #undef SLOAD
+  // row flags of the Rayleigh-number array (Ctx::rflag): at the start of a launch every row is valid (the last up sweep of a
+  // launch stores all rows, as does samsim_set_state's full first sweep)
+  __shared__ unsigned long long lds_rflag[SAMSIM_MAX_NLAYER / 64];
+  x.rflag = (lu64 *)lds_rflag;
+  for (int w = 0; w < SAMSIM_MAX_NLAYER / 64; ++w) x.rflag[w] = ~0ull;
+  // the LDS-resident scalars (each lane reads and writes only its own words: no barrier needed)
+  __shared__ double lds_scal[LD_NSLOT * SAMSIM_BLOCK];
+  c.ld = (ldouble *)lds_scal + threadIdx.x;
+#define LLOAD(field, idx) CL(field) = sc[(size_t)(idx) * nc]
+  LLOAD(grav_drain, SAMSIM_S_GRAV_DRAIN); LLOAD(grav_salt, SAMSIM_S_GRAV_SALT); LLOAD(grav_temp, SAMSIM_S_GRAV_TEMP);
+  LLOAD(melt_out1, SAMSIM_S_MELT_OUT1); LLOAD(melt_out2, SAMSIM_S_MELT_OUT2); LLOAD(melt_out3, SAMSIM_S_MELT_OUT3);
+  LLOAD(melt_err, SAMSIM_S_MELT_ERR); LLOAD(freeboard, SAMSIM_S_FREEBOARD); LLOAD(T_freeze, SAMSIM_S_T_FREEZE);
+  LLOAD(dT2m, SAMSIM_S_DT2M); LLOAD(precip_scale, SAMSIM_S_PRECIP_SCALE);
+  LLOAD(albedo, SAMSIM_S_ALBEDO); LLOAD(fl_sw, SAMSIM_S_FL_SW); LLOAD(fl_lw, SAMSIM_S_FL_LW);
+  LLOAD(T2m, SAMSIM_S_T2M); LLOAD(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LLOAD(solid_precip, SAMSIM_S_SOLID_PRECIP);
+#undef LLOAD
 
   // uniform clock (mo_data: time, i, n_time_out, time_counter) evolves identically in every lane
   double time = p.time0;
@@ -2462,6 +2675,12 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     const bool out_step = (n_time_out == p.cfg.i_time_out) || (step + 1 == 1);
     if (out_step) n_time_out = 0; else n_time_out = n_time_out + 1;
     const bool next_out = (n_time_out == p.cfg.i_time_out);
+    // `output` prints the Rayleigh numbers the step BEFORE the output step drained with (mo_grotz.f90:340-398 runs before
+    // fl_grav_drain), i.e. those this step's up sweep writes when the step after next is an output step: then, before an
+    // output step and at the end of a launch the up sweep stores every row
+    const bool next2_out = ((next_out ? 0 : n_time_out + 1) == p.cfg.i_time_out);
+    x.ray_rows_all = next_out || next2_out || (s + 1 == p.nsteps);
+    ST_MARK(ST_HEAD);
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
@@ -2481,19 +2700,24 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SSTORE(m_snow, SAMSIM_S_M_SNOW); SSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SSTORE(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SSTORE(thick_snow, SAMSIM_S_THICK_SNOW); SSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SSTORE(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
   SSTORE(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SSTORE(T_snow, SAMSIM_S_T_SNOW); SSTORE(phi_s, SAMSIM_S_PHI_S);
-  SSTORE(T_top, SAMSIM_S_T_TOP); SSTORE(melt_thick, SAMSIM_S_MELT_THICK); SSTORE(T2m, SAMSIM_S_T2M);
-  SSTORE(liquid_precip, SAMSIM_S_LIQUID_PRECIP); SSTORE(solid_precip, SAMSIM_S_SOLID_PRECIP); SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
-  SSTORE(grav_drain, SAMSIM_S_GRAV_DRAIN); SSTORE(grav_salt, SAMSIM_S_GRAV_SALT); SSTORE(grav_temp, SAMSIM_S_GRAV_TEMP);
-  SSTORE(melt_out1, SAMSIM_S_MELT_OUT1); SSTORE(melt_out2, SAMSIM_S_MELT_OUT2); SSTORE(melt_out3, SAMSIM_S_MELT_OUT3);
-  SSTORE(melt_err, SAMSIM_S_MELT_ERR); SSTORE(freeboard, SAMSIM_S_FREEBOARD); SSTORE(T_freeze, SAMSIM_S_T_FREEZE);
-  SSTORE(albedo, SAMSIM_S_ALBEDO); SSTORE(fl_sw, SAMSIM_S_FL_SW); SSTORE(fl_lw, SAMSIM_S_FL_LW);
+  SSTORE(T_top, SAMSIM_S_T_TOP); SSTORE(melt_thick, SAMSIM_S_MELT_THICK); SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
   SSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SSTORE(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
-  SSTORE(energy_stored, SAMSIM_S_ENERGY_STORED); SSTORE(freshwater, SAMSIM_S_FRESHWATER); SSTORE(total_resist, SAMSIM_S_TOTAL_RESIST);
-  SSTORE(thickness, SAMSIM_S_THICKNESS); SSTORE(bulk_salin, SAMSIM_S_BULK_SALIN);
 #undef SSTORE
+#define LSTORE(field, idx) sc[(size_t)(idx) * nc] = CL(field)
+  LSTORE(grav_drain, SAMSIM_S_GRAV_DRAIN); LSTORE(grav_salt, SAMSIM_S_GRAV_SALT); LSTORE(grav_temp, SAMSIM_S_GRAV_TEMP);
+  LSTORE(melt_out1, SAMSIM_S_MELT_OUT1); LSTORE(melt_out2, SAMSIM_S_MELT_OUT2); LSTORE(melt_out3, SAMSIM_S_MELT_OUT3);
+  LSTORE(melt_err, SAMSIM_S_MELT_ERR); LSTORE(freeboard, SAMSIM_S_FREEBOARD); LSTORE(T_freeze, SAMSIM_S_T_FREEZE);
+  LSTORE(albedo, SAMSIM_S_ALBEDO); LSTORE(fl_sw, SAMSIM_S_FL_SW); LSTORE(fl_lw, SAMSIM_S_FL_LW);
+  LSTORE(T2m, SAMSIM_S_T2M); LSTORE(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LSTORE(solid_precip, SAMSIM_S_SOLID_PRECIP);
+#undef LSTORE
   sc[(size_t)SAMSIM_S_S_BU_BOTTOM * nc] = x.S_bu_bottom;
   // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112
-  if ((K::fixed ? K::boundflux_flag : p.cfg.boundflux_flag) == 2 && (!K::general || (K::fixed ? K::atmoflux_flag : p.cfg.atmoflux_flag) == 2)) sc[(size_t)SAMSIM_S_FL_REST * nc] = c.fl_lw + 0.0 + 0.0;
+  if ((K::fixed ? K::boundflux_flag : p.cfg.boundflux_flag) == 2 && (!K::general || (K::fixed ? K::atmoflux_flag : p.cfg.atmoflux_flag) == 2)) sc[(size_t)SAMSIM_S_FL_REST * nc] = CL(fl_lw) + 0.0 + 0.0;
+#if SAMSIM_STAMPS
+  ST_MARK(ST_TAIL);
+  __syncthreads();
+  if (threadIdx.x < 32 && st_lds[threadIdx.x]) atomicAdd(&g_stamps[threadIdx.x], st_lds[threadIdx.x]);
+#endif
 }
 
 }  // namespace

@@ -1,0 +1,86 @@
+// samsim_pow.h -- x**3.10 of the permeability law (mo_grav_drain.f90:105, mo_flush.f90:119,128, mo_flood.f90:73) for x >= 0.
+//
+// x**3.1 = x*x*x * exp(0.1*log(x)).  The cube is exact to 1.5 ulp; the remaining factor has a small exponent, so a plain
+// (not double-double) logarithm is enough: an absolute error e in log(x) shows up as 0.1*e relative in the result.  log(x) =
+// E*ln2 + 2*atanh(s), s = (m-1)/(m+1), m in [sqrt(1/2), sqrt(2)); exp by n*ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial.
+// Within ~3 ulp of the correctly rounded power (tests/test_host_logic.py checks it on the CPU against math.pow with
+// this header compiled for the host; tools/div_probe checks it on the GPU), about 60 vector instructions instead of the 139 of
+// exp(3.1*log(x)) and the 214 of pow().  Included by samsim_kernels.hip and by tools/pow_host.c.
+#ifndef SAMSIM_POW_H
+#define SAMSIM_POW_H
+
+#if defined(__HIPCC__)
+#define SP_FN __device__ __forceinline__
+#define SP_FMA(a, b, c) __builtin_fma(a, b, c)
+#define SP_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
+#define SP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define SP_LDEXP(x, n) __builtin_amdgcn_ldexp(x, n)
+#define SP_RINT(x) __builtin_rint(x)
+#else
+#include <math.h>
+#define SP_FN static inline
+#define SP_FMA(a, b, c) fma(a, b, c)
+static inline double sp_frexp_mant(double x) { int e; return frexp(x, &e); }
+static inline int sp_frexp_exp(double x) { int e; (void)frexp(x, &e); return e; }
+#define SP_FREXP_MANT(x) sp_frexp_mant(x)
+#define SP_FREXP_EXP(x) sp_frexp_exp(x)
+#define SP_LDEXP(x, n) ldexp(x, n)
+#define SP_RINT(x) rint(x)
+#endif
+#ifndef SP_QUOT
+#define SP_QUOT(a, b) ((a) / (b))   // the kernel passes its own quotient (samsim_div.h)
+#endif
+
+// natural logarithm of a positive finite x (subnormals included), absolute error ~1e-16 * max(1, |log x|)
+SP_FN double sp_log(double x) {
+  double m = SP_FREXP_MANT(x);  // [0.5, 1)
+  int e = SP_FREXP_EXP(x);
+  if (m < 0.70710678118654752440) { m = m + m; e = e - 1; }
+  const double s = SP_QUOT(m - 1.0, m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 21.0;
+  p = SP_FMA(p, z, 1.0 / 19.0);
+  p = SP_FMA(p, z, 1.0 / 17.0);
+  p = SP_FMA(p, z, 1.0 / 15.0);
+  p = SP_FMA(p, z, 1.0 / 13.0);
+  p = SP_FMA(p, z, 1.0 / 11.0);
+  p = SP_FMA(p, z, 1.0 / 9.0);
+  p = SP_FMA(p, z, 1.0 / 7.0);
+  p = SP_FMA(p, z, 1.0 / 5.0);
+  p = SP_FMA(p, z, 1.0 / 3.0);
+  const double s2 = s + s;
+  const double lm = SP_FMA(s2 * z, p, s2);  // 2*atanh(s)
+  const double ed = (double)e;
+  // E*ln2 in two parts (ln2_hi has 32 trailing zero bits: E*ln2_hi is exact for |E| < 2^20)
+  return SP_FMA(ed, 0.693147180369123816490, SP_FMA(ed, 1.90821492927058770002e-10, lm));
+}
+
+// exp(y) for |y| < 700
+SP_FN double sp_exp(double y) {
+  const double n = SP_RINT(y * 1.44269504088896340736);
+  double r = SP_FMA(n, -0.693147180369123816490, y);
+  r = SP_FMA(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;           // 1/13!
+  p = SP_FMA(p, r, 1.0 / 479001600.0);
+  p = SP_FMA(p, r, 1.0 / 39916800.0);
+  p = SP_FMA(p, r, 1.0 / 3628800.0);
+  p = SP_FMA(p, r, 1.0 / 362880.0);
+  p = SP_FMA(p, r, 1.0 / 40320.0);
+  p = SP_FMA(p, r, 1.0 / 5040.0);
+  p = SP_FMA(p, r, 1.0 / 720.0);
+  p = SP_FMA(p, r, 1.0 / 120.0);
+  p = SP_FMA(p, r, 1.0 / 24.0);
+  p = SP_FMA(p, r, 1.0 / 6.0);
+  p = SP_FMA(p, r, 0.5);
+  p = SP_FMA(p, r, 1.0);
+  p = SP_FMA(p, r, 1.0);
+  return SP_LDEXP(p, (int)n);
+}
+
+// x**3.1, x >= 0 (0 -> 0; a cube that underflows gives 0 like the product 1e-17 * x**3.1 it feeds)
+SP_FN double sp_pow_3p1(double x) {
+  const double x3 = x * x * x;
+  if (!(x3 > 0.0)) return x3;
+  return x3 * sp_exp(0.1 * sp_log(x));
+}
+#endif

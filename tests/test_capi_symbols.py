@@ -73,6 +73,14 @@ def test_unsupported_configurations_are_refused_before_any_device_call():
     assert e.value.code == -2
 
 
+def test_handle_size_limit_is_checked_before_any_device_call():
+    """one handle addresses a layer array with 32-bit byte offsets: nlayer * ncol * 8 >= 4 GiB is SAMSIM_ERR_ARG (-1)"""
+    cfg, _ = tcs.testcase4(1)
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        samsim_amd.hip_solver(cfg, (1 << 29) // int(cfg.nlayer) + 1)
+    assert e.value.code == -1
+
+
 def test_product_does_not_reference_the_oracle():
     """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
     pkg = os.path.join(ROOT, "samsim_amd")

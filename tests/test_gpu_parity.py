@@ -213,6 +213,38 @@ def test_failed_columns_are_frozen_and_reported():
     a, b = g.get_state(), o.get_state()
     for n in ["H_abs", "S_abs", "T"]:
         assert rel_err(a.arr(n)[:, healthy], b.arr(n)[:, healthy]) <= RTOL
+    # a checkpoint carries the STOP codes: after save / load the frozen columns are still frozen and still reported, and the
+    # healthy ones continue bit for bit
+    import tempfile
+    from samsim_amd import checkpoint
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "frozen.chk")
+        checkpoint.save(g, path)
+        g2 = samsim_amd.hip_solver(cfg, ncol)
+        checkpoint.load(g2, path)
+    s2, step2, lay2 = g2.get_status()
+    assert np.array_equal(s2, sg) and np.array_equal(step2, stepg) and np.array_equal(lay2, layg)
+    g.step(100)
+    g2.step(100)
+    a, b = g.get_state(), g2.get_state()
+    frozen = np.nonzero(sg)[0]
+    for n in ["H_abs", "S_abs", "m", "thick", "T"]:
+        assert np.array_equal(a.arr(n)[:, healthy], b.arr(n)[:, healthy]), n
+        assert np.array_equal(a.arr(n)[:, frozen], b.arr(n)[:, frozen]), n
+    assert np.array_equal(g2.get_status()[0], sg)
+
+
+def test_launch_without_forcing_tables_is_refused():
+    """atmoflux_flag 2 reads T2m and precipitation from the tables in every step, whatever boundflux_flag says: a step before
+    samsim_set_forcing must come back as SAMSIM_ERR_ARG (the kernel is never launched on a null table)"""
+    for bf in (1, 2, 3):
+        cfg, st = tcs.testcase4(4)
+        cfg.boundflux_flag = bf
+        g = samsim_amd.hip_solver(cfg, 4)
+        g.set_state(st)
+        with pytest.raises(samsim_amd.SamsimError) as e:
+            g.step(1)
+        assert e.value.code == -1, bf
 
 
 def test_division_sequences_return_ieee_quotients():

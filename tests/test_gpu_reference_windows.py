@@ -1,0 +1,102 @@
+"""HIP path against the REFERENCE's own records, without the oracle's trajectory in between (BASELINE cfg2 / cfg3 as
+SURVEY.md section 8d specifies them).
+
+cfg3 -- SHEBA / testcase 4: the flang-built reference dumps its full state inside `output` at every output day.  For days
+sampled through open water, freeze-up, the growth season (tests/golden/tc4_tf_growth_ref.npz) and the melt seasons
+(tf_* block of tc4_ref_fullprec.npz) the HIP path is started from the reference's day-D state and must reproduce the
+reference's day-D+1 record (8641 steps later) at the parity bar.  The dump is taken in mid-step (mo_grotz.f90:363): the
+checker finishes that one step (step_part_b), everything after it runs on the GPU.
+
+cfg2 -- testcase 1 on 65 536 identical columns, the full 259 200-step run from the one-layer initial state: every column
+bitwise equal to column 0, column 0 within 1e-6 of all 72 reference records."""
+import numpy as np
+import pytest
+
+import samsim_amd
+from samsim_amd import testcases as tcs
+from tests.helpers import RTOL, golden, rel_err, sheba_forcing
+from tests.oracle_lib import oracle_solver
+from tests.test_oracle_golden import _restore_midstep
+
+pytestmark = pytest.mark.gpu
+
+
+def _windows():
+    out = []
+    for name in ("tc4_tf_growth_ref.npz", "tc4_ref_fullprec.npz"):
+        try:
+            ref = golden(name)
+        except FileNotFoundError:
+            continue
+        out += [(name, p, int(day)) for p, day in enumerate(ref["tf_days"])]
+    return out
+
+
+def test_sheba_windows_started_from_the_reference_records():
+    cfg, _ = tcs.testcase4(1)
+    o = oracle_solver(cfg, 1)
+    g = samsim_amd.hip_solver(cfg, 1)
+    for s in (o, g):
+        s.set_forcing(*sheba_forcing())
+    g.set_output_window(0, 1)
+    windows = _windows()
+    assert len(windows) >= 12 and min(d for _, _, d in windows) <= 5 and max(d for _, _, d in windows) >= 700
+    worst = 0.0
+    for name, p, day in windows:
+        ref = golden(name)
+        _restore_midstep(o, ref, 2 * p, cfg)
+        o.step_part_b()                                    # the rest of the step the reference was dumped in
+        k = o.get_clock()
+        g.set_state(o.get_state())
+        g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+        out = g.run_to_output()                            # 8640 more steps on the GPU, then the output point of day D+1
+        j = 2 * p + 1
+        assert not g.get_status()[0].any(), f"day {day}: STOP code {g.get_status()[0]}"
+        assert out.step == ref["tf_step"][j], (day, out.step, ref["tf_step"][j])
+        assert out.n_active[0] == ref["tf_N_active"][j], f"day {day}: N_active {out.n_active[0]} vs {ref['tf_N_active'][j]}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+            floor = 1e-3 if n == "H_abs" else 1e-7
+            e = rel_err(out.arr(n)[:na, 0], ref["tf_a_" + n][j, :na], floor)
+            worst = max(worst, e)
+            assert e <= RTOL, f"day {day}->{day + 1}: {n} rel err {e:.2e} vs the reference record"
+        for n, floor in (("m_snow", 1e-5), ("thick_snow", 1e-7), ("T_snow", 1e-2), ("T_top", 1e-2), ("freeboard", 1e-7),
+                         ("thickness", 1e-7), ("bulk_salin", 1e-7)):
+            e = rel_err(out.sc(n)[0], ref["tf_s_" + n][j], floor)
+            assert e <= RTOL, f"day {day}->{day + 1}: {n} rel err {e:.2e} vs the reference record"
+    print(f"worst relative deviation from the reference records over {len(windows)} windows: {worst:.2e}")
+
+
+def test_cfg2_full_run_65536_columns_against_all_72_reference_records():
+    ref = golden("tc1_ref_fullprec.npz")
+    ncol = 65536
+    cfg, st = tcs.testcase1(ncol)
+    g = samsim_amd.hip_solver(cfg, ncol)
+    g.set_state(st)
+    g.set_clock()
+    g.set_output_window(0, 1)
+    total = tcs.i_time(cfg)
+    assert total == 259200
+    done, i = 0, 0
+    while done < total:
+        n = min(g.steps_to_output(), total - done)
+        g.step(n)
+        done += n
+        if g.steps_to_output() == cfg.i_time_out + 1 or done == 1:      # an output point was just passed
+            out = g.get_output()
+            assert out.step == ref["step"][i] and out.n_active[0] == ref["N_active"][i], f"output {i}"
+            na = int(out.n_active[0])
+            for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+                floor = 1e-3 if n == "H_abs" else 1e-9
+                e = rel_err(out.arr(n)[:na, 0], ref["a_" + n][i, :na], floor)
+                assert e <= RTOL, f"output {i}: {n} rel err {e:.2e} vs the reference record"
+            for n in ["freeboard", "thickness", "bulk_salin", "energy_stored", "grav_drain", "grav_salt"]:
+                assert rel_err(out.sc(n)[0], ref["s_" + n][i], 1e-9) <= RTOL, f"output {i}: scalar {n}"
+            i += 1
+    assert i == 72
+    assert not g.get_status()[0].any()
+    s = g.get_state()
+    assert s.n_active.min() == s.n_active.max()
+    for a in range(9):   # prognostic arrays, T, phi, psi_s, psi_l, psi_g: every column equals column 0 bit for bit
+        assert (s.lay[a] == s.lay[a][:, :1]).all(), f"array {a}: replicated columns diverged"
+    assert (s.scal[:20] == s.scal[:20, :1]).all()
