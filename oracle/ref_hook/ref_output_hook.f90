@@ -23,6 +23,7 @@
 !!   SAMSIM_REF_QUIET      1 -> no dump at all (timing runs)
 !!   SAMSIM_REF_INIT       1 -> a first record of kind 3 holds the state init(testcase) left (initial profiles typed into init)
 !!   SAMSIM_REF_FLUSH / _GRAV / _FLOOD / _PRESCRIBE   override flush_flag, grav_flag, flood_flag, prescribe_flag after init
+!!   SAMSIM_REF_HARMONIC / _BOTTOM / _FREEBOARD_SNOW / _SNOW_FLUSH   override harmonic_flag, bottom_flag, freeboard_snow_flag, snow_flush_flag
 MODULE mo_output
 
   USE mo_parameters, ONLY: wp
@@ -187,7 +188,8 @@ CONTAINS
 
   SUBROUTINE output_begin(Nlayer,debug_flag,format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                           &format_melt)
-    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag, i_time_out, flush_flag, grav_flag, flood_flag, prescribe_flag
+    USE mo_data, ONLY: i_time, bgc_flag, dbg => debug_flag, i_time_out, flush_flag, grav_flag, flood_flag, prescribe_flag, &
+         harmonic_flag, bottom_flag, freeboard_snow_flag, snow_flush_flag
     INTEGER,         INTENT(in)  :: Nlayer,debug_flag
     CHARACTER*12000, INTENT(out) :: format_T,format_psi,format_thick,format_snow,format_T2m_top,format_perm,&
                                     &format_melt
@@ -213,6 +215,15 @@ CONTAINS
     IF (found) flood_flag = v
     CALL env_int('SAMSIM_REF_PRESCRIBE', v, found)
     IF (found) prescribe_flag = v
+    ! flag values no shipped testcase uses, pinned on testcase 4 (tests/golden/make_flag_fixtures.py)
+    CALL env_int('SAMSIM_REF_HARMONIC', v, found)
+    IF (found) harmonic_flag = v
+    CALL env_int('SAMSIM_REF_BOTTOM', v, found)
+    IF (found) bottom_flag = v
+    CALL env_int('SAMSIM_REF_FREEBOARD_SNOW', v, found)
+    IF (found) freeboard_snow_flag = v
+    CALL env_int('SAMSIM_REF_SNOW_FLUSH', v, found)
+    IF (found) snow_flush_flag = v
     CALL env_int('SAMSIM_REF_TRACE_FROM', v, found)
     IF (found) trace_from = v
     CALL env_int('SAMSIM_REF_TRACE_TO', v, found)

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "samsim_device.h"
 
 // SAMSIM_STAMPS (profiling builds only, never the product library): 1 = s_memtime stamps around the regions of a time step,
@@ -50,7 +52,7 @@ namespace {
 #if SAMSIM_STAMPS
 enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_TAIL,
        CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
-       CT_DRAIN_LANE, CT_DIRTY };
+       CT_DRAIN_LANE, CT_DIRTY, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B };
 struct Stamps {
   unsigned long long *acc;   // [32] in LDS, one block = one wave
   unsigned long long t0;
@@ -1299,27 +1301,21 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
 
   double flm_j = 0.0;                                  // fl_m(j) of expulsion_flux
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
+  // (requests are issued unconditionally, from a clamped row where the layer does not exist -- see sweep_up_fused)
+  const int N = c.N;
   Ld ahead = load_ld(1);
   Raw raw = finish(ahead), raw_n = raw;
-  if (Na >= 2) ahead = load_ld(2);
+  ahead = load_ld(2);                                  // nlayer >= 3 (samsim_create)
 #if SAMSIM_DAHEAD >= 3
-  Ld ahead2 = ahead;                                   // layer j+2 (ahead = layer j+1): requested two iterations before use
-  if (Na >= 3) ahead2 = load_ld(3);
+  Ld ahead2 = load_ld(3);                              // layer j+2 (ahead = layer j+1): requested two iterations before use
 #endif
   Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
-  const int jmax = wave_max(Na);
-  for (int j = 1; j <= jmax; ++j) {
-    ISA_MARK("D_ITER_BEGIN");
-    if (j > Na) continue;
-    ST_COUNT(CT_DOWN_TRIPS, 1);
-    if (j < Na) raw_n = finish(ahead);
-#if SAMSIM_DAHEAD >= 3
-    ahead = ahead2;
-    if (j + 3 <= Na) ahead2 = load_ld(j + 3);
-#else
-    if (j + 2 <= Na) ahead = load_ld(j + 2);
-#endif
+  // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
+  // runs after the loop (once per wave, every lane with its own j), so that the loop body -- the interior layers -- carries
+  // neither the bottom-layer work (gas -> ocean water, the bottom turbulence with its exp and two pow) nor its registers.
+  auto layer = [&](const int j, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     // ---- A(j)
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
@@ -1330,7 +1326,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     const double T = raw.T, S_br = raw.S_br;
     if (do_beer) {
       if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
-      if (j == Na) c.frad = temp2 - temp2 * e;
+      if (LAST) c.frad = temp2 - temp2 * e;
       temp2 = temp2 * e;
     }
     double flm_next;
@@ -1361,7 +1357,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     const double S_bu = quot(S_abs, m);  // refreshed bulk salinity, mo_grotz.f90:333-335
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_j = flm_next;
-    if (j == Na) {
+    if (LAST) {
       if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
         const double t2 = psi_g * thick * rho_l;
         m = m + t2;
@@ -1374,9 +1370,10 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       }
     }
     // ---- B(j)
+    ST_MARK(ST_D_A);
     sum_before += S_abs;
     double flup = cum;
-    if (j <= Na - 1) {
+    if (!LAST) {
       const double ray = raw.ray;
       if (ray > ray_crit && S_br > raw_n.S_br) {
         const double psi_s = ex.psi_s;
@@ -1414,9 +1411,26 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       flup_pp = prev.flup;
     }
     prev.T = T; prev.S_bu = S_bu; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
+    ST_MARK(ST_D_B);
+  };
+  const int jmax = wave_max(Na);
+  for (int j = 1; j < jmax; ++j) {                     // the interior layers j < N_active
+    ISA_MARK("D_ITER_BEGIN");
+    ST_MARK(ST_DFUSED);
+    if (j >= Na) continue;
+    ST_COUNT(CT_DOWN_TRIPS, 1);
+    raw_n = finish(ahead);
+#if SAMSIM_DAHEAD >= 3
+    ahead = ahead2;
+    ahead2 = load_ld(j + 3 <= N ? j + 3 : N);
+#else
+    ahead = load_ld(j + 2 <= N ? j + 2 : N);
+#endif
+    layer(j, std::false_type{});
     raw = raw_n;
     ISA_MARK("D_ITER_END");
   }
+  layer(Na, std::true_type{});                         // the bottom layer (this sweep only runs with N_active >= 2)
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
     prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
@@ -1587,23 +1601,27 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // the top of iteration k (as it was up to round 1 for these two) exposes the full HBM latency in every iteration; made at the
   // top of iteration k+1 it has a whole iteration of arithmetic (a Newton chain of ~3.6 evaluations) to arrive.
   struct UL { double T, th, hr, H, m, S; };
+  // (every request is issued unconditionally, from a clamped row where the layer does not exist: the hardware counts
+  // outstanding memory operations in order, and the compiler can only wait for "all but the N youngest" when every path
+  // through the loop body issues the same operations -- one conditional request and it falls back to draining them all)
   auto load_ul = [&](int j) -> UL {
     UL r;
     r.T = LAY(SAMSIM_A_T, j); r.th = LAY(SAMSIM_A_THICK, j);
-    r.hr = (j >= 2) ? LAY(D_HR, j) : hr_top;
+    const double hr_j = LAY(D_HR, j >= 2 ? j : 2);
+    r.hr = (j >= 2) ? hr_j : hr_top;
     r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.S = LAY(SAMSIM_A_S_ABS, j);
     return r;
   };
-  UL cur = load_ul(Na), nxt = cur, nn = cur;   // layers k, k-1, k-2
-  if (Na >= 2) nxt = load_ul(Na - 1);
-  const int kmax = wave_max(Na);
-  for (int k = kmax; k >= 1; --k) {
-    ISA_MARK("U_ITER_BEGIN");
-    if (k > Na) continue;
-    if (k >= 3) nn = load_ul(k - 2);
+  UL cur = load_ul(Na), nxt = load_ul(Na >= 2 ? Na - 1 : 1), nn = nxt;   // layers k, k-1, k-2
+  bool alive = true;
+  // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
+  // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
+  // thin-snow coupling (up to 200 getT pairs) nor its registers.
+  auto body = [&](const int k, auto top_tag) {
+    constexpr bool TOP = decltype(top_tag)::value;
     double flq_k;
     const double T_k = cur.T, th_k = cur.th, hr_k = cur.hr, H_k = cur.H, m_k = cur.m, S_k = cur.S;
-    if (k > 1) {
+    if (!TOP) {
       const double R = nxt.hr + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
       flq_k = quot(T_k - nxt.T, R);
     } else {
@@ -1614,12 +1632,12 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     H_abs = H_abs + (flq_below - flq_k) * dt;
     H_abs = H_abs + c.frad * dt;
     const double m = m_k;
-    if (k == 1) {  // snow treatment, mo_heat_fluxes.f90:291-303
+    if (TOP) {  // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
         c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
         LAY(SAMSIM_A_H_ABS, 1) = H_abs;
         snow_coupling<K>(c, x);
-        if (c.status) return;
+        if (c.status) { alive = false; return; }
         H_abs = LAY(SAMSIM_A_H_ABS, 1);
       } else if (c.thick_snow >= thick_min) {
         c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
@@ -1631,7 +1649,8 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     double S_bu, H;
     per_mass(S_abs, H_abs, m, S_bu, H);
     double T, phi = 0.0;
-    ISA_MARK("U_GETT_BEGIN");
+    if (!TOP) { ISA_MARK("U_GETT_BEGIN"); }
+    ST_MARK(ST_U_HEAD);
 #if SAMSIM_STAMPS == 2
     int evals = 1;
     int rr = getT(s, H, S_bu, T_test, T, phi, &evals);
@@ -1642,26 +1661,37 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
 #else
     int rr = getT(s, H, S_bu, T_test, T, phi);
 #endif
-    ISA_MARK("U_GETT_END");
+    if (!TOP) { ISA_MARK("U_GETT_END"); }
+    ST_MARK(ST_U_GETT);
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
     LAY(SAMSIM_A_T, k) = T;
     // the down sweeps recompute phi from T; the array is kept for its readers: the regrid trigger and layer_dynamics (bottom
     // two active layers), layer 1, the output snapshot and get_state
-    if (store_phi || k == 1 || k >= Na - 1) LAY(SAMSIM_A_PHI, k) = phi;
-    if (k > 1) {
+    if (store_phi || TOP || k >= Na - 1) LAY(SAMSIM_A_PHI, k) = phi;
+    if (!TOP) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
-      double S_bu_n = S_bu;
       if (S_abs < 0.0) {
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu_n, m, th_k, r, true);
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, r, true);
     }
     flq_below = flq_k;
+    ST_MARK(ST_U_TAIL);
+  };
+  const int kmax = wave_max(Na);
+  for (int k = kmax; k >= 2; --k) {
+    ISA_MARK("U_ITER_BEGIN");
+    ST_MARK(ST_UP);
+    if (k > Na) continue;
+    nn = load_ul(k >= 3 ? k - 2 : 1);
+    body(k, std::false_type{});
     cur = nxt; nxt = nn;
     ISA_MARK("U_ITER_END");
   }
+  body(1, std::true_type{});
+  if (!alive) return;
   // hand-over block for prologue_top_layer of the next step
   SPEC(SP_MINP) = r.minp; SPEC(SP_STP) = r.stp; SPEC(SP_ST) = r.st;
   SPEC(SP_BOT) = r.bot; SPEC(SP_BOTTERM) = r.botterm; SPEC(SP_PERM_BOT) = r.perm_bot;

@@ -18,9 +18,10 @@ def load_oracle() -> C.CDLL:
     global _lib
     if _lib is None:
         src = os.path.join(ORACLE_DIR, "samsim_oracle.c")
-        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        so = os.environ.get("SAMSIM_ORACLE_SO", ORACLE_SO)     # the sanitizer build, tests/test_oracle_sanitized.py
+        if so == ORACLE_SO and (not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
-        _lib = C.CDLL(ORACLE_SO)
+        _lib = C.CDLL(so)
         d = C.c_double
         _lib.oracle_func_S_br.restype = d
         _lib.oracle_func_S_br.argtypes = [C.c_int, d, d, C.c_int]

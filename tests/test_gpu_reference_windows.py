@@ -100,3 +100,39 @@ def test_cfg2_full_run_65536_columns_against_all_72_reference_records():
     for a in range(9):   # prognostic arrays, T, phi, psi_s, psi_l, psi_g: every column equals column 0 bit for bit
         assert (s.lay[a] == s.lay[a][:, :1]).all(), f"array {a}: replicated columns diverged"
     assert (s.scal[:20] == s.scal[:20, :1]).all()
+
+
+@pytest.mark.parametrize("name", ["harmonic1", "freeboard_snow1", "snow_flush0", "bottom2"])
+def test_unshipped_flag_values_from_the_reference_records(name):
+    """harmonic_flag 1, freeboard_snow_flag 1, snow_flush_flag 0, bottom_flag 2 (run-time-flag instantiation of the kernel): from
+    the reference's day-D state of a testcase-4 run with that flag overridden to its day-D+1 record, days through growth and
+    the first melt season (the oracle is bitwise on the same fixtures, tests/test_oracle_golden.py)"""
+    from tests.test_oracle_golden import FLAG_VARIANTS
+    ref = golden(f"tc4_flag_{name}_ref.npz")
+    cfg, _ = tcs.testcase4(1)
+    for k, v in FLAG_VARIANTS[name].items():
+        setattr(cfg, k, v)
+    o = oracle_solver(cfg, 1)
+    g = samsim_amd.hip_solver(cfg, 1)
+    for s in (o, g):
+        s.set_forcing(*sheba_forcing())
+    g.set_output_window(0, 1)
+    for p, day in enumerate(ref["tf_days"]):
+        _restore_midstep(o, ref, 2 * p, cfg)
+        o.step_part_b()
+        k = o.get_clock()
+        g.set_state(o.get_state())
+        g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+        out = g.run_to_output()
+        j = 2 * p + 1
+        assert not g.get_status()[0].any(), f"{name} day {day}: STOP code {g.get_status()[0]}"
+        assert out.step == ref["tf_step"][j] and out.n_active[0] == ref["tf_N_active"][j], f"{name} day {day}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+            floor = 1e-3 if n == "H_abs" else 1e-7
+            e = rel_err(out.arr(n)[:na, 0], ref["tf_a_" + n][j, :na], floor)
+            assert e <= RTOL, f"{name} day {day}->{day + 1}: {n} rel err {e:.2e} vs the reference record"
+        for n, floor in (("m_snow", 1e-5), ("thick_snow", 1e-7), ("T_snow", 1e-2), ("T_top", 1e-2), ("freeboard", 1e-7),
+                         ("thickness", 1e-7)):
+            e = rel_err(out.sc(n)[0], ref["tf_s_" + n][j], floor)
+            assert e <= RTOL, f"{name} day {day}->{day + 1}: {n} rel err {e:.2e} vs the reference record"

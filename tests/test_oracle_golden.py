@@ -132,10 +132,12 @@ def _restore_midstep(o, ref, j, cfg):
                 time_counter=int(ref["tf_time_counter"][j]), n_outputs=0)
 
 
-def test_tc4_melt_season_teacher_forced():
+@pytest.mark.parametrize("fixture", ["tc4_ref_fullprec.npz", "tc4_tf_growth_ref.npz"])
+def test_tc4_teacher_forced_from_reference_records(fixture):
     """SHEBA is chaotic across melt seasons: restart the oracle from the reference's own state at
-    output day D (melt season) and require agreement at output day D+1 (8641 steps later) at the parity bar"""
-    ref = golden("tc4_ref_fullprec.npz")
+    output day D and require agreement at output day D+1 (8641 steps later) at the parity bar -- melt-season days
+    (tc4_ref_fullprec.npz) and days through open water, freeze-up and growth (tc4_tf_growth_ref.npz)"""
+    ref = golden(fixture)
     cfg, st = tcs.testcase4(1)
     for p, day in enumerate(ref["tf_days"]):
         o = oracle_solver(cfg, 1)
@@ -154,6 +156,43 @@ def test_tc4_melt_season_teacher_forced():
             e = rel_err(out.sc(n)[0], ref["tf_s_" + n][j], 1e-9)
             assert e <= 1e-9, f"day {day}->{day + 1}: {n} rel err {e:.2e}"
         o.close()
+
+
+FLAG_VARIANTS = {"harmonic1": dict(harmonic_flag=1), "freeboard_snow1": dict(freeboard_snow_flag=1),
+                 "snow_flush0": dict(snow_flush_flag=0), "bottom2": dict(bottom_flag=2)}
+
+
+@pytest.mark.parametrize("name", list(FLAG_VARIANTS))
+def test_tc4_unshipped_flag_values_against_the_reference(name):
+    """harmonic_flag 1 (MINVAL permeability in the Rayleigh number), freeboard_snow_flag 1, snow_flush_flag 0 and bottom_flag 2
+    are used by no shipped testcase; the reference was run on testcase 4 with one of them overridden after init
+    (tests/golden/make_flag_fixtures.py).  From open water, bit for bit at every output day of the first 75, then from the
+    reference's own state at day D to its day D+1 record for days through growth and the first melt season."""
+    ref = golden(f"tc4_flag_{name}_ref.npz")
+    cfg, st = tcs.testcase4(1)
+    for k, v in FLAG_VARIANTS[name].items():
+        setattr(cfg, k, v)
+    o = oracle_solver(cfg, 1)
+    o.set_forcing(*sheba_forcing())
+    o.set_state(st)
+    o.set_clock()
+    days = {int(d): j for j, d in enumerate(ref["day_index"])}
+    for day in range(1, 76):
+        _compare_output(o.run_to_output(), ref, day - 1, days.get(day), f"{name} day {day}")
+    assert not o.get_status()[0].any()
+    for p, day in enumerate(ref["tf_days"]):
+        _restore_midstep(o, ref, 2 * p, cfg)
+        o.step_part_b()
+        out = o.run_to_output()
+        j = 2 * p + 1
+        assert out.step == ref["tf_step"][j] and out.n_active[0] == ref["tf_N_active"][j], f"{name} day {day}"
+        na = int(out.n_active[0])
+        for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+            e = rel_err(out.arr(n)[:na, 0], ref["tf_a_" + n][j, :na], 1e-9)
+            assert e <= 1e-9, f"{name} day {day}->{day + 1}: {n} rel err {e:.2e}"
+        for n in ["m_snow", "thick_snow", "T_snow", "T_top", "freeboard", "thickness"]:
+            e = rel_err(out.sc(n)[0], ref["tf_s_" + n][j], 1e-9)
+            assert e <= 1e-9, f"{name} day {day}->{day + 1}: {n} rel err {e:.2e}"
 
 
 def _compare_output(out, ref, i, j, tag, layers=LAYERS + ["perm", "flush_v", "flush_h"], prefix="all_"):

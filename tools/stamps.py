@@ -18,7 +18,7 @@ import bench  # noqa: E402
 
 NAMES = ["t_prologue", "t_down_fused", "t_down_unfused", "t_surface", "t_up", "t_post", "t_head", "t_tail",
          "wave_steps", "fused", "unfused", "up_trips", "newton_wave", "newton_lane", "lanes", "down_trips", "drain_wave",
-         "drain_lane", "dirty"]
+         "drain_lane", "dirty", "_19", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC"]
 
 
 def main():
@@ -50,9 +50,10 @@ def main():
     out = {"lib": os.environ.get("SAMSIM_HIP_LIB", "default"), "mean_launch_ms": float(np.mean(ms)),
            "launches": args.launches, "nlayer": args.nlayer}
     out.update({n: v[i] for i, n in enumerate(NAMES)})
-    tsum = v[:8].sum()
+    tidx = list(range(8)) + list(range(20, 25))
+    tsum = v[tidx].sum()
     if tsum > 0:
-        out["share"] = {n: round(v[i] / tsum, 4) for i, n in enumerate(NAMES[:8])}
+        out["share"] = {NAMES[i]: round(v[i] / tsum, 4) for i in tidx}
     if v[11] > 0:
         out["newton_evals_per_cell_wave_max"] = v[12] / v[11]
         out["newton_evals_per_cell_lane_mean"] = v[13] / (v[11] * 64)
