@@ -130,6 +130,11 @@ MODULE mo_samsim_capi
        INTEGER(c_int64_t), INTENT(out) :: step(*)
        INTEGER(c_int32_t), INTENT(out) :: layer(*)
      END FUNCTION
+     INTEGER(c_int) FUNCTION samsim_set_ocean(h, dfl_q_bottom_col, S_bu_bottom_col) BIND(C, name='samsim_set_ocean')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       TYPE(c_ptr), VALUE :: dfl_q_bottom_col, S_bu_bottom_col   ! [ncol] each, or c_null_ptr
+     END FUNCTION
      INTEGER(c_int) FUNCTION samsim_set_status(h, status, step, layer, col0, ncols) BIND(C, name='samsim_set_status')
        IMPORT
        TYPE(c_ptr), VALUE :: h

@@ -155,6 +155,14 @@ int samsim_set_forcing_sites(samsim_handle *h, int32_t nsites, int32_t len, cons
                              const double *T2m, const double *precip, const int32_t *site_of_column,
                              const double *dT2m_col, const double *precip_scale_col);
 
+/* The water below a grid of columns (the reference has one column and sets both as scalars of mo_data):
+ * dfl_q_bottom_col[c] ([ncol] or NULL) is added to the oceanic heat flux sub_test4 assigns every step (testcases 4 and 7,
+ * mo_testcase_specifics.f90:197-202: fl_q_bottom_c = -7 sin(2 pi t / year) + 7 + dfl_q_bottom_c); S_bu_bottom_col[c] ([ncol] or
+ * NULL) replaces cfg.S_bu_bottom for column c wherever the reference reads S_bu_bottom (mass_transfer's ghost cell, flooding,
+ * bottom turbulence, bottom growth; tank_flag 1 -- with tank_flag 2 the tank budget owns it, mo_grotz.f90:573-575).  A column
+ * with offset 0 and cfg.S_bu_bottom is the reference's column.  NULL, NULL switches both off. */
+int samsim_set_ocean(samsim_handle *h, const double *dfl_q_bottom_col, const double *S_bu_bottom_col);
+
 /* initial state of init(testcase) (mo_init.f90:141-1978) or a checkpoint; col0 and s->ncol select a window.
  * The two perturbation slots SAMSIM_S_DT2M / SAMSIM_S_PRECIP_SCALE are owned by samsim_set_forcing: set_state
  * ignores them, get_state returns them. */

@@ -57,6 +57,9 @@ typedef struct column {
   double energy_stored, freshwater, total_resist, thickness, bulk_salin;
   double dT2m, precip_scale;
   double S_bu_bottom;            /* salinity of the water below the ice: cfg value, or the tank budget (tank_flag 2) */
+  double dflq;                   /* samsim_set_ocean: offset on the oceanic heat flux of sub_test4 (0 unless given) */
+  int ocean_sbu;                 /* samsim_set_ocean: S_bu_bottom is this column's own value (survives set_state) */
+  double ocean_sbu_value;
   /* passive tracers, mo_data.f90:181-193 */
   int n_bgc;
   double *bgc[SAMSIM_MAX_NBGC];  /* bgc_abs(:, t), 1-based */
@@ -1558,7 +1561,10 @@ static void step_part_b(column *c) {
   /* testcase specifics :503-565 */
   if (g->testcase == 1) sub_test1(c->time, &c->T_top);
   else if (g->testcase == 3) { c->liquid_precip = 0.0; c->solid_precip = 0.15 / 86400.0 / 356.0; }  /* sub_test3, :172-187 */
-  else if (g->testcase == 4 || g->testcase == 7) sub_test4(c->time, &c->fl_q_bottom);
+  else if (g->testcase == 4 || g->testcase == 7) {
+    sub_test4(c->time, &c->fl_q_bottom);
+    if (c->dflq != 0.0) c->fl_q_bottom = c->fl_q_bottom + c->dflq;   /* a grid of columns: samsim_set_ocean */
+  }
   else if (g->testcase == 5 && c->step + 1 == 2) { for (k = 1; k <= N; k++) S_abs[k] = 5.0 * m[k]; }   /* mo_grotz.f90:543-544 */
   else if (g->testcase == 2) sub_test2(c->time, &c->T2m);
   else if (g->testcase == 6) sub_test6(c->time, &c->T2m);
@@ -1897,7 +1903,7 @@ int oracle_set_state(oracle_handle *h, const samsim_state_soa *s, int64_t col0) 
     }
     /* the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing and are not touched by set_state */
     for (int j = 0; j < SAMSIM_S_DT2M; j++) *scal_slot(c, j) = s->scal[(size_t)j * nc + i];
-    if (h->cfg.tank_flag != 2) c->S_bu_bottom = h->cfg.S_bu_bottom;
+    if (h->cfg.tank_flag != 2) c->S_bu_bottom = c->ocean_sbu ? c->ocean_sbu_value : h->cfg.S_bu_bottom;
     c->N_active = s->n_active[i];
     if (c->N_active < 1 || c->N_active > N) return SAMSIM_ERR_ARG;
   }
@@ -2033,6 +2039,21 @@ int oracle_get_status(oracle_handle *h, int32_t *status, int64_t *step, int32_t 
     if (status) status[i] = h->cols[i].status;
     if (step) step[i] = h->cols[i].err_step;
     if (layer) layer[i] = h->cols[i].err_layer;
+  }
+  return SAMSIM_OK;
+}
+
+/* the water below a grid of columns: the checker mirrors samsim_set_ocean */
+int oracle_set_ocean(oracle_handle *h, const double *dfl_q_bottom_col, const double *S_bu_bottom_col) {
+  if (!h) return SAMSIM_ERR_ARG;
+  if (dfl_q_bottom_col && h->cfg.testcase != 4 && h->cfg.testcase != 7) return SAMSIM_ERR_UNSUPPORTED;
+  if (S_bu_bottom_col && h->cfg.tank_flag == 2) return SAMSIM_ERR_UNSUPPORTED;
+  for (int64_t i = 0; i < h->ncol; i++) {
+    column *c = &h->cols[i];
+    c->dflq = dfl_q_bottom_col ? dfl_q_bottom_col[i] : 0.0;
+    c->ocean_sbu = S_bu_bottom_col != NULL;
+    c->ocean_sbu_value = S_bu_bottom_col ? S_bu_bottom_col[i] : 0.0;
+    if (h->cfg.tank_flag != 2) c->S_bu_bottom = c->ocean_sbu ? c->ocean_sbu_value : h->cfg.S_bu_bottom;
   }
   return SAMSIM_OK;
 }

@@ -43,6 +43,7 @@ int64_t oracle_steps_to_output(oracle_handle *h);
 int  oracle_set_output_window(oracle_handle *h, int64_t col0, int64_t ncols);
 int  oracle_get_output(oracle_handle *h, samsim_output_soa *o);
 int  oracle_get_status(oracle_handle *h, int32_t *status, int64_t *step, int32_t *layer);
+int  oracle_set_ocean(oracle_handle *h, const double *dfl_q_bottom_col, const double *S_bu_bottom_col);
 int  oracle_set_status(oracle_handle *h, const int32_t *status, const int64_t *step, const int32_t *layer, int64_t col0, int64_t ncols);
 int  oracle_get_work(oracle_handle *h, int64_t *layer_cell_updates, int64_t *column_steps);
 int  oracle_set_tracers(oracle_handle *h, int32_t n_bgc, const double *bgc_bottom, const double *bgc_total);

@@ -186,6 +186,7 @@ class Solver:
         sig = {
             "set_forcing": [vp, i32, dp, dp, dp, dp, dp, dp],
             "set_forcing_sites": [vp, i32, i32, dp, dp, dp, dp, C.POINTER(C.c_int32), dp, dp],
+            "set_ocean": [vp, dp, dp],
             "set_state": [vp, C.POINTER(StateSoA), i64], "get_state": [vp, C.POINTER(StateSoA), i64],
             "set_clock": [vp, C.POINTER(Clock)], "get_clock": [vp, C.POINTER(Clock)],
             "step": [vp, i64], "set_output_window": [vp, i64, i64], "get_output": [vp, C.POINTER(OutputSoA)],
@@ -237,6 +238,15 @@ class Solver:
         self._chk(self._f("set_forcing_sites")(self._h, nsites, n, *[_dp(a) for a in arrs], _ip(site),
                                                _dp(d) if d is not None else None, _dp(p) if p is not None else None),
                   "set_forcing_sites")
+
+    def set_ocean(self, dfl_q_bottom=None, S_bu_bottom=None):
+        """the water below a grid of columns (samsim_set_ocean): per-column offset on the oceanic heat flux sub_test4 sets every
+        step, per-column salinity of the water below (tank_flag 1); None switches a part off"""
+        d = None if dfl_q_bottom is None else np.ascontiguousarray(dfl_q_bottom, dtype=np.float64)
+        s = None if S_bu_bottom is None else np.ascontiguousarray(S_bu_bottom, dtype=np.float64)
+        assert d is None or d.shape == (self.ncol,)
+        assert s is None or s.shape == (self.ncol,)
+        self._chk(self._f("set_ocean")(self._h, _dp(d) if d is not None else None, _dp(s) if s is not None else None), "set_ocean")
 
     def set_state(self, st: State, col0: int = 0):
         s = st._c()

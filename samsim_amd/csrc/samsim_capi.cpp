@@ -55,6 +55,7 @@ struct samsim_handle {
   double *f_sw = nullptr, *f_lw = nullptr, *f_T2m = nullptr, *f_precip = nullptr;
   int32_t flen = 0, nsites = 1;
   int32_t *site = nullptr;     // [ncol] forcing set of each column (nsites > 1)
+  double *ocean_dflq = nullptr, *ocean_sbu = nullptr;   // samsim_set_ocean: per-column oceanic heat-flux offset / salinity below
   double *out_lay = nullptr, *out_scal = nullptr;
   int32_t *out_n_active = nullptr;
   long long out_col0 = 0, out_ncols = 0;
@@ -212,6 +213,7 @@ int launch(samsim_handle *h, long long nsteps) {
   p.spec = h->spec; p.flags = h->flags;
   p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
   p.nsites = h->nsites; p.site = h->site;
+  p.ocean_dflq = h->ocean_dflq; p.ocean_sbu = h->ocean_sbu;
   p.ncol = h->ncol;
   p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
   p.nsteps = nsteps;
@@ -328,6 +330,7 @@ void samsim_destroy(samsim_handle *h) {
   (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat);
   (void)hipFree(h->bgc); (void)hipFree(h->bgc_bot); (void)hipFree(h->bfl); (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
   (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip); (void)hipFree(h->site);
+  (void)hipFree(h->ocean_dflq); (void)hipFree(h->ocean_sbu);
   (void)hipFree(h->out_lay); (void)hipFree(h->out_scal); (void)hipFree(h->out_n_active);
   (void)hipFree(h->d_params);
   if (h->h_params) (void)hipHostFree(h->h_params);
@@ -375,6 +378,28 @@ int samsim_set_forcing_sites(samsim_handle *h, int32_t nsites, int32_t len, cons
   } else {
     HIPCHK(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return SAMSIM_OK;
+}
+
+int samsim_set_ocean(samsim_handle *h, const double *dfl_q_bottom_col, const double *S_bu_bottom_col) {
+  int rc = use(h);
+  if (rc) return rc;
+  // the offset rides on the flux sub_test4 sets every step; the salinity replaces cfg.S_bu_bottom, which the tank budget owns with tank_flag 2
+  if (dfl_q_bottom_col && h->cfg.testcase != 4 && h->cfg.testcase != 7) return SAMSIM_ERR_UNSUPPORTED;
+  if (S_bu_bottom_col && h->cfg.tank_flag == 2) return SAMSIM_ERR_UNSUPPORTED;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t nc = (size_t)h->ncol;
+  (void)hipFree(h->ocean_dflq); (void)hipFree(h->ocean_sbu);
+  h->ocean_dflq = h->ocean_sbu = nullptr;
+  if (dfl_q_bottom_col) {
+    HIPCHK(dalloc(&h->ocean_dflq, nc));
+    HIPCHK(hipMemcpy(h->ocean_dflq, dfl_q_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice));
+  }
+  if (S_bu_bottom_col) {
+    for (size_t i = 0; i < nc; ++i) if (!(S_bu_bottom_col[i] >= 0.0)) return SAMSIM_ERR_ARG;
+    HIPCHK(dalloc(&h->ocean_sbu, nc));
+    HIPCHK(hipMemcpy(h->ocean_sbu, S_bu_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice));
   }
   return SAMSIM_OK;
 }

@@ -172,6 +172,7 @@ typedef unsigned long long lu64;
 enum lds_slot {
   LD_grav_drain = 0, LD_grav_salt, LD_grav_temp, LD_melt_out1, LD_melt_out2, LD_melt_out3, LD_melt_err,
   LD_freeboard, LD_T_freeze, LD_dT2m, LD_precip_scale, LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
+  LD_T_top_rad,   // per-step hand-over, not a slot of the scalar block
   LD_NSLOT
 };
 #define CL(f) c.ld[LD_##f * SAMSIM_BLOCK]
@@ -207,6 +208,8 @@ struct Col {
   // per-step temporaries that cross sweeps
   double fl_Q1;      // fl_Q(1)
   double frad;       // fl_rad(N_active)
+  double flq2;       // fl_Q(2), handed from the down sweep (which applies the conductive update of layers >= 2) to the top-layer block
+  double esum;       // SUM(H_abs before - H_abs after the conductive update) over layers >= 2 (energy assert, mo_heat_fluxes.f90:265-310)
   double min_psi_s;  // MINVAL(psi_s(1:N_active)) of this step's Expulsion
   double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
@@ -232,6 +235,14 @@ struct Col {
 #endif
 // SAMSIM_HORNER: the liquidus polynomial in Horner form (5 operations instead of 9 per evaluation, about six evaluations per
 // layer-cell; 1 % on the default bench); 0 = the reference's c2*T + c3*T**2 + c4*T**3
+// SAMSIM_THICK_RULE: the semi-adaptive grid (mo_layer_dynamics.f90) keeps every layer but the first at thick_0, except the
+// N_middle elastic layers, which all share one value (they receive the same increments in the same order).  Where a column's
+// thicknesses follow that rule (COLF_REGULAR, checked whenever the full first sweep runs) the fused sweeps and the Beer-law pass
+// form thick(k) from thick(1), thick(N_top+1) and thick_0 instead of streaming the array: three of the fourteen row accesses per
+// layer-cell.  A column that does not follow it (a hand-made state) loads the array; 0 = always load.
+#ifndef SAMSIM_THICK_RULE
+#define SAMSIM_THICK_RULE 1
+#endif
 // SAMSIM_DAHEAD: how many layers ahead of the arithmetic the fused down sweep requests its operands (2 or 3)
 #ifndef SAMSIM_DAHEAD
 #define SAMSIM_DAHEAD 2
@@ -338,7 +349,7 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 // evaluations per layer-cell on the bench ensemble, all of them on the critical path of the up sweep.  Only taken where the
 // reference's clamps of S_br (1e-9 / 1e-10) are inactive (sb > 1e-4); 0 = two divisions.
 #ifndef SAMSIM_NEWTON1
-#define SAMSIM_NEWTON1 0
+#define SAMSIM_NEWTON1 1
 #endif
 // one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1
 __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
@@ -505,9 +516,14 @@ struct Ctx {
   double p17, p14, tf_c3;
   // salinity of the water below the ice: cfg.S_bu_bottom (uniform), or the column's tank budget with tank_flag 2 (mo_grotz.f90:573)
   double S_bu_bottom;
+  double rho_bottom;   // func_density(T_bottom, S_bu_bottom) of sub_turb_flux, evaluated once per launch where the water below is uniform
   // passive tracers (bgc_flag 2, KGeneric only): amounts [n_bgc][N][ncol], concentration below the ice [n_bgc][ncol], this
   // step's brine fluxes [BFL_NROW][N][ncol], snapshot of the output window
   int soff;   // start of this column's forcing set in the tables (0 unless samsim_set_forcing_sites gave several)
+  // the water below a grid of columns (samsim_set_ocean, K::sites instantiations): offset added to the oceanic heat flux the
+  // testcase sets every step (sub_test4), and whether S_bu_bottom above is this column's own value
+  double dflq;
+  bool ocean_sbu;
   gdouble *bgc, *bgc_bot, *bfl, *out_bgc, *out_bgc_bot;
   int n_bgc;
   double bgc_total0;
@@ -526,6 +542,19 @@ struct Ctx {
 #define BFL(r, k) (x.bfl + ((size_t)(r) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 // tracers exist only in the run-time-flag instantiation; in the fixed ones the test folds to false
 #define HAS_BGC (K::general && x.n_bgc > 0)
+
+// density of the water below the ice (sub_turb_flux, mo_functions.f90:355): the same number in every step of every column unless
+// the tank budget (tank_flag 2) moves S_bu_bottom
+template <class K>
+__device__ __forceinline__ double ocean_density(const Ctx &x) {
+  if ((K::fixed ? K::tank_flag : x.p->cfg.tank_flag) == 2 || (K::sites && x.ocean_sbu)) return func_density(x.p->cfg.T_bottom, x.S_bu_bottom);
+  return x.rho_bottom;
+}
+
+// thick(k), k >= 2, of a column that follows the grid rule; th_mid = thick(N_top+1)
+__device__ __forceinline__ double thick_by_rule(int k, int n_top, int n_middle, double th_mid, double thick_0) {
+  return (k > n_top && k <= n_top + n_middle) ? th_mid : thick_0;
+}
 
 // Does row k of the Rayleigh-number array hold this column's current value?  Row 1 is written by the first sweep of every step
 // (prologue_top_layer / sweep_thermo_expulsion), the other rows by the last up sweep where flagged (Ctx::rflag), and all of them by
@@ -851,10 +880,13 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
   // loads one layer ahead of the arithmetic, as in the fused sweeps
   double H_n = LAY(SAMSIM_A_H_ABS, Na), m_n = LAY(SAMSIM_A_M, Na), th_n = LAY(SAMSIM_A_THICK, Na), S_n = LAY(SAMSIM_A_S_ABS, Na);
+  bool regular = true;
+  const double th_mid_rule = LAY(SAMSIM_A_THICK, g.n_top + 1);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
     const double H_abs = H_n, m = m_n, thick = th_n;
+    if (k >= 2 && thick != thick_by_rule(k, g.n_top, g.n_middle, th_mid_rule, g.thick_0)) regular = false;
     double S_abs = S_n;
     if (k > 1) { H_n = LAY(SAMSIM_A_H_ABS, k - 1); m_n = LAY(SAMSIM_A_M, k - 1); th_n = LAY(SAMSIM_A_THICK, k - 1); S_n = LAY(SAMSIM_A_S_ABS, k - 1); }
     if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
@@ -874,6 +906,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   }
   c.min_psi_s = r.min_psi_s;
   c.buoy_s = r.buoy_s;
+  c.flags = regular ? (c.flags | COLF_REGULAR) : (c.flags & ~COLF_REGULAR);
   if (rc) STOPC(rc, rc_layer);
 }
 
@@ -948,7 +981,6 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
     LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
     LAY(SAMSIM_A_PSI_G, k) = psi_g;
-    if (k >= 2) LAY(D_HR, k) = thick / (2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));  // hand-over to the up sweep
     m = m + flm_next - flm_k;
     LAY(SAMSIM_A_M, k) = m;
     if (HAS_BGC) BFL(BFL_E, k) = transfer ? -flm_next : 0.0;
@@ -1241,15 +1273,62 @@ __device__ RARE void sweep_grav_drain_simple(Col &c, const Ctx &x, bool do_beer,
 
 // Beer-law absorption alone (no gravity drainage this step): fl_rad(N_active), mo_heat_fluxes.f90:151-155
 template <class K>
-__device__ RARE void sweep_beer(Col &c, double beer0) {
+__device__ RARE void sweep_beer(Col &c, const Ctx &x, double beer0) {
+  const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
+#if SAMSIM_THICK_RULE
+  const bool regular = (c.flags & COLF_REGULAR) != 0;
+  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+#endif
   for (int k = 1; k <= Na; ++k) {
+#if SAMSIM_THICK_RULE
+    const double thick = (regular && k >= 2) ? thick_by_rule(k, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, k);
+#else
     const double thick = LAY(SAMSIM_A_THICK, k);
+#endif
     if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
     if (k == Na) c.frad = temp2 - temp2 * e;
     temp2 = temp2 * e;
   }
+}
+
+// Conductive update of sub_heat_fluxes (mo_heat_fluxes.f90:272-285) for layers 2..N_active on the unfused path, top -> bottom from
+// the arrays (old temperatures, this step's volume fractions, the thickness flooding may just have changed): the fused down sweep
+// applies it on the fly, so the up sweep never does.  Layer 1 is left to the top-layer block (fl_Q(1) comes from the surface
+// balance); fl_Q(2) and the two energy sums are handed on in the column struct.
+template <class K>
+__device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
+  const int Na = c.Na;
+  const double dt = x.p->cfg.dt;
+  const double frad_dt = c.frad * dt;
+  double esum = 0.0;
+  c.flq2 = 0.0;
+  if (Na >= 2) {
+    double T_up = LAY(SAMSIM_A_T, 1);
+    double hr_up = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
+    double flq_k = 0.0;   // fl_Q(k)
+    for (int k = 2; k <= Na; ++k) {
+      const double T = LAY(SAMSIM_A_T, k);
+      const double hr = LAY(SAMSIM_A_THICK, k) / (2.0 * (LAY(SAMSIM_A_PSI_S, k) * k_s + LAY(SAMSIM_A_PSI_L, k) * k_l));
+      const double flq = (T - T_up) / (hr_up + hr);
+      if (k == 2) c.flq2 = flq;
+      if (k >= 3) {   // layer k-1: both of its fluxes are known now
+        const double H_b = LAY(SAMSIM_A_H_ABS, k - 1);
+        double H_abs = H_b + (flq - flq_k) * dt;
+        H_abs = H_abs + frad_dt;
+        esum += H_b - H_abs;
+        LAY(SAMSIM_A_H_ABS, k - 1) = H_abs;
+      }
+      T_up = T; hr_up = hr; flq_k = flq;
+    }
+    const double H_b = LAY(SAMSIM_A_H_ABS, Na);   // bottom layer: fl_Q(N_active+1) = fl_q_bottom
+    double H_abs = H_b + (c.fl_q_bottom - flq_k) * dt;
+    H_abs = H_abs + frad_dt;
+    esum += H_b - H_abs;
+    LAY(SAMSIM_A_H_ABS, Na) = H_abs;
+  }
+  c.esum = esum;
 }
 
 // ---------------------------------------------------------------- D: fused down sweep (P2 + P3), top -> bottom
@@ -1262,14 +1341,16 @@ __device__ RARE void sweep_beer(Col &c, double beer0) {
 // j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
 // T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
 template <class K>
-__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_beer, double beer0, bool store_psi) {
+__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_psi) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
   const double dt = g.dt;
   double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300, buoy_g = 0.0;
-  double temp2 = beer0, e = 0.0, th_prev = -1.0;
   int stop_layer = 0;
+  // conductive heat fluxes (sub_heat_fluxes, mo_heat_fluxes.f90:272-285): see C(j-1) below
+  double hr_up = 0.0, flq_up = 0.0;      // half resistance thick/(2k) of layer j-1, fl_Q(j-1)
+  double esum = 0.0;                     // SUM(H_abs before - after) of the conductive update, for the energy assert
 
   // The sweeps are latency bound (a wave waits on memory for most of its life), so the loads run ahead of the arithmetic:
   // the six values of layer j+2 are requested at the top of iteration j and first touched in iteration j+1 (S_br of the
@@ -1279,13 +1360,21 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   struct Ld { double T, S_abs, m, H_abs, thick, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
   unsigned long long rbits = x.rflag[0];   // row flags of rows 1..64; the next word is fetched when j crosses into it
+#if SAMSIM_THICK_RULE
+  const bool regular = (c.flags & COLF_REGULAR) != 0;
+  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+#endif
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAY(SAMSIM_A_T, j);
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.m = LAY(SAMSIM_A_M, j);
     r.H_abs = LAY(SAMSIM_A_H_ABS, j);
+#if SAMSIM_THICK_RULE
+    r.thick = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, j);
+#else
     r.thick = LAY(SAMSIM_A_THICK, j);
+#endif
     if (((j - 1) & 63) == 0 && j > 1) rbits = x.rflag[(j - 1) >> 6];
     r.ray = (j <= Na - 1 && (j == 1 || c.ray_all || ((rbits >> ((j - 1) & 63)) & 1ull) != 0ull)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
     return r;
@@ -1297,7 +1386,10 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
   };
-  struct Lay { double T, S_bu, S_abs, H_abs, m, flup; };
+  // (SA, mA: salt and mass right after A(j).  Their quotient, the refreshed bulk salinity of mo_grotz.f90:333-335, is only
+  // read where brine actually moves -- the drainage test of B(j) and the return-flow transfers of C -- so it is formed there:
+  // same operands, same quotient, one division less in the nine layers out of ten that do not drain)
+  struct Lay { double T, SA, mA, S_abs, H_abs, m, flup; };
 
   double flm_j = 0.0;                                  // fl_m(j) of expulsion_flux
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
@@ -1309,7 +1401,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
 #if SAMSIM_DAHEAD >= 3
   Ld ahead2 = load_ld(3);                              // layer j+2 (ahead = layer j+1): requested two iterations before use
 #endif
-  Lay prev = {0, 0, 0, 0, 0, 0};                       // layer j-1 after A and B, waiting for C
+  Lay prev = {0, 0, 1, 0, 0, 0, 0};                    // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
   // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
   // runs after the loop (once per wave, every lane with its own j), so that the loop body -- the interior layers -- carries
@@ -1324,17 +1416,12 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
-    if (do_beer) {
-      if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
-      if (LAST) c.frad = temp2 - temp2 * e;
-      temp2 = temp2 * e;
-    }
     double flm_next;
     if (j == 1 || psi_g < (double)0.001f) {
       flm_next = (j == 1) ? -V_ex * rho_l : -V_ex * rho_l + flm_j;
     } else {
       flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
-      psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
+      psi_g = dmax(quot(psi_g * thick - V_ex, thick), 0.0);
     }
     if (psi_g > 0.0) buoy_g += psi_g * thick;
     // The up sweep only needs the layer's half resistance thick/(2k) (sub_fl_Q, mo_thermo_functions.f90:201-223); the three
@@ -1344,7 +1431,11 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
       LAY(SAMSIM_A_PSI_G, j) = psi_g;
     }
-    if (j >= 2) LAY(D_HR, j) = quot(thick, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
+    // sub_fl_Q (mo_thermo_functions.f90:201-223): fl_Q(j) = (T(j) - T(j-1)) / (thick(j-1)/(2k(j-1)) + thick(j)/(2k(j))) with the
+    // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op)
+    const double hr = quot(thick, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
+    const double flq = (j >= 2) ? quot(T - prev.T, hr_up + hr) : 0.0;
+    if (j == 2) c.flq2 = flq;
     m = m + flm_next - flm_j;
     if (flm_next < 0.0) {
       H_abs = H_abs + flm_next * T * c_l;
@@ -1354,7 +1445,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       H_abs = H_abs - flm_j * T_up * c_l;
       S_abs = S_abs - dmax(flm_j * S_br_up, -S_abs_up);
     }
-    const double S_bu = quot(S_abs, m);  // refreshed bulk salinity, mo_grotz.f90:333-335
+    const double SA = S_abs, mA = m;     // S_bu = SA / mA: refreshed bulk salinity, mo_grotz.f90:333-335 (formed where it is read)
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_j = flm_next;
     if (LAST) {
@@ -1365,7 +1456,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
         H_abs = H_abs + t2 * c_l * g.T_bottom;
       }
       if (CFG(turb_flag) == 2) {  // sub_turb_flux
-        const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, x.S_bu_bottom) + func_density(T, S_abs / m))) * dt;
+        const double turb = Turb_A * exp(Turb_B * (-ocean_density<K>(x) + func_density(T, S_abs / m))) * dt;
         S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       }
     }
@@ -1377,7 +1468,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       const double ray = raw.ray;
       if (ray > ray_crit && S_br > raw_n.S_br) {
         const double psi_s = ex.psi_s;
-        if (psi_s > 0.001 && S_bu > 0.1) {  // S_bu = S_abs/m of this layer, formed above (j < N_active: nothing changed since)
+        if (psi_s > 0.001 && quot(SA, mA) > 0.1) {  // S_bu of this layer (j < N_active: nothing changed since A)
           ST_COUNT(CT_DRAIN_WAVE, 1);
           ST_COUNT(CT_DRAIN_LANE, (unsigned long long)__popcll(__ballot(1)));
           const double psi_l = ex.psi_l;
@@ -1398,11 +1489,22 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
     if (j > 1) {
       if (prev.flup > 0.0) {
         prev.H_abs = prev.H_abs + prev.flup * T * c_l;
-        prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, T, S_bu), S_abs);
+        prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, T, quot(SA, mA)), S_abs);
       }
       if (flup_pp > 0.0) {
         prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
-        prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
+        prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, quot(prev.SA, prev.mA)), prev.S_abs);
+      }
+      // The brine transports of layer j-1 are complete: what the reference does next to its enthalpy is the explicit conductive
+      // update of sub_heat_fluxes, H_abs(k) += (fl_Q(k+1) - fl_Q(k))*dt, then += fl_rad(N_active)*dt (mo_heat_fluxes.f90:277-285:
+      // sic, the bottom layer's absorption in every layer).  Both fluxes are at hand here -- old temperatures, this step's volume
+      // fractions -- so the down sweep applies it and the up sweep neither reads T and the half resistances nor writes H_abs.
+      // Layer 1 takes fl_Q(1) from the surface balance, which needs the finished layer 1: the top-layer block does it.
+      if (j - 1 >= 2) {
+        const double H_b = prev.H_abs;
+        prev.H_abs = prev.H_abs + (flq - flq_up) * dt;
+        prev.H_abs = prev.H_abs + c.frad * dt;
+        esum += H_b - prev.H_abs;
       }
       LAY(SAMSIM_A_M, j - 1) = prev.m;
       LAY(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
@@ -1410,7 +1512,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
       minS = dmin(minS, prev.S_abs);
       flup_pp = prev.flup;
     }
-    prev.T = T; prev.S_bu = S_bu; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
+    hr_up = hr; flq_up = flq;
+    prev.T = T; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
     ST_MARK(ST_D_B);
   };
   const int jmax = wave_max(Na);
@@ -1438,10 +1541,17 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool do_b
   }
   if (flup_pp > 0.0) {
     prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
-    prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, prev.S_bu), prev.S_abs);
+    prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, quot(prev.SA, prev.mA)), prev.S_abs);
   }
   CL(grav_drain) = CL(grav_drain) + prev.flup;
   if (CFG(grav_heat_flag) == 2) prev.H_abs = prev.H_abs + heat_loss - prev.flup * c_l * g.T_bottom;
+  // conductive update of the bottom layer: fl_Q(N_active+1) = fl_q_bottom (this sweep only runs with N_active >= 2)
+  {
+    const double H_b = prev.H_abs;
+    prev.H_abs = prev.H_abs + (c.fl_q_bottom - flq_up) * dt;
+    prev.H_abs = prev.H_abs + c.frad * dt;
+    c.esum = esum + (H_b - prev.H_abs);
+  }
   LAY(SAMSIM_A_M, Na) = prev.m;
   LAY(SAMSIM_A_S_ABS, Na) = prev.S_abs;
   LAY(SAMSIM_A_H_ABS, Na) = prev.H_abs;
@@ -1504,8 +1614,10 @@ __device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, 
   return temp1;
 }
 
+// T_top_rad: the radiative surface temperature when the caller has formed it already this step (the fused path evaluates it
+// before the down sweep to decide what to store; same inputs, same value), else pass have_rad = false
 template <class K>
-__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
+__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x, bool have_rad = false, double T_top_rad = 0.0) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
@@ -1533,7 +1645,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
   double temp1;
-  c.T_top = radiative_T_top(c, fl_rest, T1, thick_min);
+  c.T_top = have_rad ? T_top_rad : radiative_T_top(c, fl_rest, T1, thick_min);
 
   if (c.thick_snow >= thick_min / 100.0) CL(T_freeze) = 0.0;
   else CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
@@ -1580,8 +1692,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   const bool keep_ray = next_is_output && col >= x.out_col0 && col < x.out_col0 + x.out_ncols;
   const double H_abs_snow_before = c.H_abs_snow;
-  double sum_before = 0.0, sum_after = 0.0;
-  double flq_below = c.fl_q_bottom;  // fl_Q(k+1)
+  double esum = c.esum;   // SUM(H_abs before - after the conductive update) over the layers >= 2, from the down sweep
   double T_test = g.T_bottom;
   int rc = 0, rc_layer = 0;
   RayScan r;
@@ -1592,23 +1703,24 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   }
   for (int w = 0; w <= (c.N - 1) >> 6; ++w) x.rflag[w] = 0ull;   // every lane writes the same zeros
   if (do_ray && Na <= c.N - 1 && x.ray_rows_all) LAY(SAMSIM_A_RAY, Na) = 0.0;   // (read by `output` only)
-  // half resistance thick/(2k) of a layer, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp, mo_thermo_functions.f90:213:
-  // a no-op for finite psi_g): the same quotient serves fl_Q(k+1) and fl_Q(k).  Layers >= 2 take it from the down sweep;
-  // layer 1 forms it here, because flooding and snow-ice formation change thick(1) between the two sweeps.
-  const double hr_top = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
-  // The six values of a layer -- old T, thick, half resistance, H_abs, m, S_abs -- are requested TWO iterations before the
-  // layer's own iteration: the stencil of iteration k reads T and the half resistance of layer k-1 at once, so a request made at
-  // the top of iteration k (as it was up to round 1 for these two) exposes the full HBM latency in every iteration; made at the
-  // top of iteration k+1 it has a whole iteration of arithmetic (a Newton chain of ~3.6 evaluations) to arrive.
-  struct UL { double T, th, hr, H, m, S; };
-  // (every request is issued unconditionally, from a clamped row where the layer does not exist: the hardware counts
-  // outstanding memory operations in order, and the compiler can only wait for "all but the N youngest" when every path
-  // through the loop body issues the same operations -- one conditional request and it falls back to draining them all)
+  // The conductive update of layers >= 2 has been applied by the down sweep (sweep_down_fused / sweep_heat_down), which also
+  // hands over fl_Q(2) and the energy sums: this sweep reads the finished enthalpy and runs the second getT chain -- and, for
+  // layers N_active..2, the first sweep of the next step.  Its operands (H_abs, m, S_abs, thick of a layer) are requested TWO
+  // iterations ahead, unconditionally and from a clamped row where the layer does not exist: the hardware counts outstanding
+  // memory operations in order, and the compiler can only wait for "all but the N youngest" when every path through the loop
+  // body issues the same operations -- one conditional request and it falls back to draining them all.
+  struct UL { double th, H, m, S; };
+#if SAMSIM_THICK_RULE
+  const bool regular = (c.flags & COLF_REGULAR) != 0;
+  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+#endif
   auto load_ul = [&](int j) -> UL {
     UL r;
-    r.T = LAY(SAMSIM_A_T, j); r.th = LAY(SAMSIM_A_THICK, j);
-    const double hr_j = LAY(D_HR, j >= 2 ? j : 2);
-    r.hr = (j >= 2) ? hr_j : hr_top;
+#if SAMSIM_THICK_RULE
+    r.th = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, j);
+#else
+    r.th = LAY(SAMSIM_A_THICK, j);
+#endif
     r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.S = LAY(SAMSIM_A_S_ABS, j);
     return r;
   };
@@ -1619,20 +1731,16 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // thin-snow coupling (up to 200 getT pairs) nor its registers.
   auto body = [&](const int k, auto top_tag) {
     constexpr bool TOP = decltype(top_tag)::value;
-    double flq_k;
-    const double T_k = cur.T, th_k = cur.th, hr_k = cur.hr, H_k = cur.H, m_k = cur.m, S_k = cur.S;
-    if (!TOP) {
-      const double R = nxt.hr + hr_k;  // sub_fl_Q, mo_thermo_functions.f90:201-223
-      flq_k = quot(T_k - nxt.T, R);
-    } else {
-      flq_k = c.fl_Q1;
-    }
+    const double th_k = cur.th, H_k = cur.H, m_k = cur.m, S_k = cur.S;
     double H_abs = H_k;
-    sum_before += H_abs;
-    H_abs = H_abs + (flq_below - flq_k) * dt;
-    H_abs = H_abs + c.frad * dt;
     const double m = m_k;
-    if (TOP) {  // snow treatment, mo_heat_fluxes.f90:291-303
+    if (TOP) {
+      // conductive update of layer 1: fl_Q(2) from the down sweep (fl_q_bottom under a single layer), fl_Q(1) from the surface balance
+      const double flq_below = (Na >= 2) ? c.flq2 : c.fl_q_bottom;
+      const double H_b = H_abs;
+      H_abs = H_abs + (flq_below - c.fl_Q1) * dt;
+      H_abs = H_abs + c.frad * dt;
+      // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
         c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
         LAY(SAMSIM_A_H_ABS, 1) = H_abs;
@@ -1642,9 +1750,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       } else if (c.thick_snow >= thick_min) {
         c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
       }
+      esum += H_b - H_abs;   // (after the thin-snow coupling, which moves enthalpy between the snow and layer 1)
+      LAY(SAMSIM_A_H_ABS, 1) = H_abs;
     }
-    sum_after += H_abs;
-    LAY(SAMSIM_A_H_ABS, k) = H_abs;
     double S_abs = S_k;
     double S_bu, H;
     per_mass(S_abs, H_abs, m, S_bu, H);
@@ -1677,7 +1785,6 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       }
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, r, true);
     }
-    flq_below = flq_k;
     ST_MARK(ST_U_TAIL);
   };
   const int kmax = wave_max(Na);
@@ -1696,14 +1803,14 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   SPEC(SP_MINP) = r.minp; SPEC(SP_STP) = r.stp; SPEC(SP_ST) = r.st;
   SPEC(SP_BOT) = r.bot; SPEC(SP_BOTTERM) = r.botterm; SPEC(SP_PERM_BOT) = r.perm_bot;
   SPEC(SP_SBR_BOT) = r.S_br_bot; SPEC(SP_BUOY_S) = r.buoy_s; SPEC(SP_MIN_PSI_S) = r.min_psi_s;
-  // energy conservation assert, mo_heat_fluxes.f90:265-310
-  double temp1 = sum_before + H_abs_snow_before;
-  temp1 = temp1 + (double)Na * (c.frad * dt);
-  if (thin_snow || c.thick_snow >= thick_min) temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
-  else temp1 = temp1 + c.fl_q_bottom * dt - c.fl_Q1 * dt;
-  const double temp2 = sum_after + c.H_abs_snow;
+  // energy conservation assert, mo_heat_fluxes.f90:265-310: (SUM(H_abs) + H_abs_snow) before + what went in - the same after,
+  // with the two sums taken as one sum of per-layer differences
+  double bal = esum + (H_abs_snow_before - c.H_abs_snow);
+  bal = bal + (double)Na * (c.frad * dt);
+  if (thin_snow || c.thick_snow >= thick_min) bal = bal + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
+  else bal = bal + c.fl_q_bottom * dt - c.fl_Q1 * dt;
   if (rc) STOPC(rc, rc_layer);
-  if (fabs((temp1 - temp2) / dt) > 0.00001) STOPC(431, 0);
+  if (fabs(bal / dt) > 0.00001) STOPC(431, 0);
 }
 
 // ---------------------------------------------------------------- melt film, mo_functions.f90:386-474
@@ -2256,7 +2363,7 @@ __device__ RARE void flush4(Col &c, const Ctx &x) {
 
 // testcase specifics that only touch scalars, mo_grotz.f90:503-565
 template <class K>
-__device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g, double time) {
+__device__ __forceinline__ void testcase_scalars(Col &c, const Ctx &x, const samsim_config &g, double time) {
   if (CFG(testcase) == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
     for (int n = 1; n <= 20; ++n) {
       if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
@@ -2266,6 +2373,7 @@ __device__ __forceinline__ void testcase_scalars(Col &c, const samsim_config &g,
     CL(solid_precip) = 0.15 / 86400.0 / 356.0;
   } else if (CFG(testcase) == 4 || CFG(testcase) == 7) {  // sub_test4, :197-202
     c.fl_q_bottom = -7.0 * sin(time * (2.0 * pi_f) / (86400.0 * 365.0)) + 7.0;
+    if (K::sites) c.fl_q_bottom = c.fl_q_bottom + x.dflq;   // samsim_set_ocean: this column's offset (0 unless given)
   } else if (K::general && CFG(testcase) == 2) {  // sub_test2, :99-111
     if (time > 86400.0 * 25.0) CL(T2m) = 15.0;
     else if (time > 86400.0 * 15.0) CL(T2m) = 1.0;
@@ -2333,7 +2441,7 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     if (CFG(turb_flag) == 2) {
       const double m = LAY(SAMSIM_A_M, Na), T = LAY(SAMSIM_A_T, Na);
       double S_abs = LAY(SAMSIM_A_S_ABS, Na);
-      const double turb = Turb_A * exp(Turb_B * (-func_density(g.T_bottom, x.S_bu_bottom) + func_density(T, S_abs / m))) * g.dt;
+      const double turb = Turb_A * exp(Turb_B * (-ocean_density<K>(x) + func_density(T, S_abs / m))) * g.dt;
       S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       LAY(SAMSIM_A_S_ABS, Na) = S_abs;
       if (HAS_BGC) {  // the tracers of the bottom layer mix with the same coefficient, :358-360
@@ -2342,7 +2450,7 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     }
 
     // testcase specifics, mo_grotz.f90:503-565 (the scalar ones commute with the gravity drainage sweep below)
-    testcase_scalars<K>(c, g, time);
+    testcase_scalars<K>(c, x, g, time);
 
     // gravity drainage (mo_grotz.f90:463-477) fused with the Beer-law pass of sub_heat_fluxes
     const double beer0 = radiation_header<K>(c, x, time, tc);
@@ -2354,12 +2462,14 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     } else if (K::general && CFG(grav_flag) == 3 && Na > 1) {
       sweep_grav_drain_simple<K>(c, x, do_beer, beer0);
     } else if (do_beer) {
-      sweep_beer<K>(c, beer0);
+      sweep_beer<K>(c, x, beer0);
     }
     if (K::general && CFG(prescribe_flag) == 2) prescribe_salinity<K>(c, x);  // mo_grotz.f90:482-497
     if (K::general && CFG(testcase) == 5 && c.step + 1 == 2) {  // mo_grotz.f90:543-544
       for (int k = 1; k <= N; ++k) LAY(SAMSIM_A_S_ABS, k) = 5.0 * LAY(SAMSIM_A_M, k);
     }
+    // conductive update of layers >= 2 (sub_heat_fluxes, mo_grotz.f90:584; the tank budget in between only reads S_abs and m)
+    sweep_heat_down<K>(c, x);
 }
 
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
@@ -2403,7 +2513,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   c.ray_all = (c.flags & COLF_DIRTY) != 0;
   if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); sweep_thermo_expulsion<K>(c, x); }
   else prologue_top_layer<K>(c, x);
-  c.flags = 0;
+  c.flags &= COLF_REGULAR;
   if (c.status) return;
 
   int Na = c.Na;
@@ -2421,11 +2531,12 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   ST_MARK(ST_PRO);
   ST_COUNT(CT_WAVESTEPS, 1);
   ST_COUNT(CT_LANES, (unsigned long long)__popcll(__ballot(1)));
+  bool have_rad = false;   // the radiative surface temperature of this step has been formed already (CL(T_top_rad))
   if (fused) {
     ST_COUNT(CT_FUSED, 1);
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
-    testcase_scalars<K>(c, g, time);
+    testcase_scalars<K>(c, x, g, time);
     const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
     // Who reads the psi_s / psi_l / psi_g arrays this sweep would store?  The vital signs at the next output point, a
@@ -2435,18 +2546,25 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // than -8 C or already wet) and the late readers stop the column (code 9001) should the prediction ever have been
     // wrong.  Everything else (layer 1 itself, the up sweep's conductivities) is handed over separately.
     bool store_psi = true;
+#ifndef SAMSIM_STORE_PSI_ALWAYS
     if (K::fixed && K::boundflux_flag == 2 && K::flush_flag == 5) {
       const double th1 = LAY(SAMSIM_A_THICK, 1), m1 = LAY(SAMSIM_A_M, 1);
       const Expelled e1 = expulsion(LAY(SAMSIM_A_PHI, 1), th1, m1);
       const double T_fr = (c.thick_snow >= g.thick_min / 100.0) ? 0.0 : func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / m1, CFG(salt_flag), x.tf_c3);
       const double T_top_est = radiative_T_top(c, CL(fl_lw) + 0.0 + 0.0, LAY(SAMSIM_A_T, 1), g.thick_min);
+      have_rad = true;
+      CL(T_top_rad) = T_top_est;   // surface_flux forms the same value from the same inputs: handed on through LDS
       store_psi = next_out || last_step || e1.psi_s < psi_s_top_min + 0.05 || T_top_est >= T_fr - 1.0 ||
                   (c.thick_snow > 0.0 && (c.T_snow > -8.0 || c.melt_thick_snow > 0.0));
     }
+#endif
     // without melt-water flushing (flush_flag 1) nothing on the fused path reads them but the vital signs and get_state
     if (K::fixed && K::flush_flag == 1) store_psi = next_out || last_step;
     c.psi_full = store_psi;
-    sweep_down_fused<K>(c, x, do_beer, beer0, store_psi);
+    // fl_rad(N_active) enters the conductive update of every layer (mo_heat_fluxes.f90:282-285), which the down sweep applies as
+    // it goes: the Beer-law product over the layer thicknesses (a pass over one array) comes first
+    if (do_beer) sweep_beer<K>(c, x, beer0);
+    sweep_down_fused<K>(c, x, store_psi);
     ST_MARK(ST_DFUSED);
     if (c.status) return;
   } else {
@@ -2471,7 +2589,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   }
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
-  surface_flux<K>(c, x);
+  surface_flux<K>(c, x, have_rad, have_rad ? (double)CL(T_top_rad) : 0.0);
   ST_MARK(ST_SURF);
   sweep_up_fused<K>(c, x, col, next_out, next_out || last_step);
   ST_MARK(ST_UP);
@@ -2638,9 +2756,13 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
   x.n_bgc = K::general ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
   x.soff = (K::sites && p.nsites > 1) ? site[col] * p.flen : 0;
+  x.dflq = (K::sites && p.ocean_dflq) ? p.ocean_dflq[col] : 0.0;
+  x.ocean_sbu = K::sites && p.ocean_sbu != nullptr;
   x.out_col0 = p.out_col0; x.out_ncols = p.out_ncols;
   x.p17 = p.p17; x.p14 = p.p14; x.tf_c3 = p.tf_c3;
   x.S_bu_bottom = (K::general && (K::fixed ? K::tank_flag : p.cfg.tank_flag) == 2) ? scal[(size_t)SAMSIM_S_S_BU_BOTTOM * (size_t)p.ncol + (size_t)col] : p.cfg.S_bu_bottom;
+  if (K::sites && p.ocean_sbu && (K::fixed ? K::tank_flag : p.cfg.tank_flag) != 2) x.S_bu_bottom = p.ocean_sbu[col];
+  x.rho_bottom = func_density(p.cfg.T_bottom, p.cfg.S_bu_bottom);
   if ((K::fixed ? K::salt_flag : p.cfg.salt_flag) == 1) x.salt = Salt{-18.7, -0.519, -0.00535, -21.4, -0.886, -0.0170};
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
@@ -2758,7 +2880,7 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
   // tracers exist in the run-time-flag instantiation only; several forcing sets there and in the SHEBA one
-  const bool tracers = g.bgc_flag == 2, sites = hp->nsites > 1;
+  const bool tracers = g.bgc_flag == 2, sites = hp->nsites > 1 || hp->ocean_dflq || hp->ocean_sbu;
   auto kernel = (!tracers && !sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
                 : (!tracers && sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KShebaSites>
                 : (!tracers && !sites && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;

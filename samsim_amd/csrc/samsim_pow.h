@@ -16,6 +16,22 @@
 #define SP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define SP_LDEXP(x, n) __builtin_amdgcn_ldexp(x, n)
 #define SP_RINT(x) __builtin_rint(x)
+// a*b + C and a*C + b with the constant C read from a scalar register pair: left to itself the compiler materialises every
+// polynomial coefficient in a vector register pair (two v_mov_b32 per coefficient, as many vector instructions as the fma they
+// feed -- on this machine every vector instruction, 32- or 64-bit, occupies the SIMD for four cycles); two s_mov_b32 issue on the
+// scalar unit beside the vector work.  Same operation, same rounding.
+__device__ __forceinline__ double sp_fma_vvs(double a, double b, double c_const) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
+  return r;
+}
+__device__ __forceinline__ double sp_fma_vsv(double a, double c_const, double b) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c_const), "v"(b));
+  return r;
+}
+#define SP_FMA_C(a, b, C) sp_fma_vvs(a, b, C)
+#define SP_FMA_MC(a, C, b) sp_fma_vsv(a, C, b)
 #else
 #include <math.h>
 #define SP_FN static inline
@@ -26,6 +42,8 @@ static inline int sp_frexp_exp(double x) { int e; (void)frexp(x, &e); return e; 
 #define SP_FREXP_EXP(x) sp_frexp_exp(x)
 #define SP_LDEXP(x, n) ldexp(x, n)
 #define SP_RINT(x) rint(x)
+#define SP_FMA_C(a, b, C) fma(a, b, C)
+#define SP_FMA_MC(a, C, b) fma(a, C, b)
 #endif
 #ifndef SP_QUOT
 #define SP_QUOT(a, b) ((a) / (b))   // the kernel passes its own quotient (samsim_div.h)
@@ -39,38 +57,38 @@ SP_FN double sp_log(double x) {
   const double s = SP_QUOT(m - 1.0, m + 1.0);
   const double z = s * s;
   double p = 1.0 / 21.0;
-  p = SP_FMA(p, z, 1.0 / 19.0);
-  p = SP_FMA(p, z, 1.0 / 17.0);
-  p = SP_FMA(p, z, 1.0 / 15.0);
-  p = SP_FMA(p, z, 1.0 / 13.0);
-  p = SP_FMA(p, z, 1.0 / 11.0);
-  p = SP_FMA(p, z, 1.0 / 9.0);
-  p = SP_FMA(p, z, 1.0 / 7.0);
-  p = SP_FMA(p, z, 1.0 / 5.0);
-  p = SP_FMA(p, z, 1.0 / 3.0);
+  p = SP_FMA_C(p, z, 1.0 / 19.0);
+  p = SP_FMA_C(p, z, 1.0 / 17.0);
+  p = SP_FMA_C(p, z, 1.0 / 15.0);
+  p = SP_FMA_C(p, z, 1.0 / 13.0);
+  p = SP_FMA_C(p, z, 1.0 / 11.0);
+  p = SP_FMA_C(p, z, 1.0 / 9.0);
+  p = SP_FMA_C(p, z, 1.0 / 7.0);
+  p = SP_FMA_C(p, z, 1.0 / 5.0);
+  p = SP_FMA_C(p, z, 1.0 / 3.0);
   const double s2 = s + s;
   const double lm = SP_FMA(s2 * z, p, s2);  // 2*atanh(s)
   const double ed = (double)e;
   // E*ln2 in two parts (ln2_hi has 32 trailing zero bits: E*ln2_hi is exact for |E| < 2^20)
-  return SP_FMA(ed, 0.693147180369123816490, SP_FMA(ed, 1.90821492927058770002e-10, lm));
+  return SP_FMA_MC(ed, 0.693147180369123816490, SP_FMA_MC(ed, 1.90821492927058770002e-10, lm));
 }
 
 // exp(y) for |y| < 700
 SP_FN double sp_exp(double y) {
   const double n = SP_RINT(y * 1.44269504088896340736);
-  double r = SP_FMA(n, -0.693147180369123816490, y);
-  r = SP_FMA(n, -1.90821492927058770002e-10, r);
+  double r = SP_FMA_MC(n, -0.693147180369123816490, y);
+  r = SP_FMA_MC(n, -1.90821492927058770002e-10, r);
   double p = 1.0 / 6227020800.0;           // 1/13!
-  p = SP_FMA(p, r, 1.0 / 479001600.0);
-  p = SP_FMA(p, r, 1.0 / 39916800.0);
-  p = SP_FMA(p, r, 1.0 / 3628800.0);
-  p = SP_FMA(p, r, 1.0 / 362880.0);
-  p = SP_FMA(p, r, 1.0 / 40320.0);
-  p = SP_FMA(p, r, 1.0 / 5040.0);
-  p = SP_FMA(p, r, 1.0 / 720.0);
-  p = SP_FMA(p, r, 1.0 / 120.0);
-  p = SP_FMA(p, r, 1.0 / 24.0);
-  p = SP_FMA(p, r, 1.0 / 6.0);
+  p = SP_FMA_C(p, r, 1.0 / 479001600.0);
+  p = SP_FMA_C(p, r, 1.0 / 39916800.0);
+  p = SP_FMA_C(p, r, 1.0 / 3628800.0);
+  p = SP_FMA_C(p, r, 1.0 / 362880.0);
+  p = SP_FMA_C(p, r, 1.0 / 40320.0);
+  p = SP_FMA_C(p, r, 1.0 / 5040.0);
+  p = SP_FMA_C(p, r, 1.0 / 720.0);
+  p = SP_FMA_C(p, r, 1.0 / 120.0);
+  p = SP_FMA_C(p, r, 1.0 / 24.0);
+  p = SP_FMA_C(p, r, 1.0 / 6.0);
   p = SP_FMA(p, r, 0.5);
   p = SP_FMA(p, r, 1.0);
   p = SP_FMA(p, r, 1.0);

@@ -438,3 +438,58 @@ def test_sheba_melt_season_teacher_forced_windows():
         else:
             o.step(8640)
     assert min(na_seen) < 50 and max(na_seen) == 100, na_seen   # the regrids really happened inside the tested span
+
+
+def test_per_column_ocean_grid_of_columns():
+    """samsim_set_ocean: a grid of 64 columns over oceans of different heat flux and salinity (KShebaSites instantiation), from
+    open water through freeze-up against the oracle; column 0 (no offset, cfg.S_bu_bottom) equals the single-ocean run bitwise"""
+    ncol = 64
+    cfg, st = tcs.testcase4(ncol)
+    rng = np.random.default_rng(11)
+    dq = rng.uniform(-4.0, 8.0, ncol)
+    sb = rng.uniform(28.0, 36.0, ncol)
+    dq[0], sb[0] = 0.0, cfg.S_bu_bottom
+    g, o = pair(cfg, ncol, st, forcing=sheba_forcing())
+    for s in (g, o):
+        s.set_ocean(dq, sb)
+    # free run through open water and the first days of ice (day 64), then windows restarted from the checker's state every four
+    # days up to day 100: freeze-up with first snow amplifies round-off in a free run (SURVEY.md section 4), a window does not
+    n = 8641 * 64
+    g.step(n)
+    o.step(n)
+    sg, so = check(g, o, "ocean grid, day 64")
+    assert np.array_equal(sg.sc("S_bu_bottom"), sb)
+    spread = set()
+    while o.get_clock().step < 8641 * 100:
+        k = o.get_clock()
+        g.set_state(o.get_state())
+        g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
+        g.step(1500)
+        o.step(1500)
+        sg, so = check(g, o, f"ocean grid, window at step {k.step}")
+        spread.update(int(v) for v in so.n_active)
+        o.step(8641 * 4 - 1500)
+    assert len(spread) > 8                                                  # the oceans spread the ensemble
+    assert abs(float(sg.sc("fl_q_bottom")[5] - sg.sc("fl_q_bottom")[0]) - dq[5]) < 1e-12
+    # column 0 (no offset, cfg.S_bu_bottom) is the single-ocean column, bit for bit
+    n = 8641 * 64
+    g2 = samsim_amd.hip_solver(cfg, ncol)
+    dT, ps = tcs.ensemble_perturbation(ncol)
+    g2.set_forcing(*sheba_forcing(), dT, ps)
+    g2.set_ocean(dq, sb)
+    g2.set_state(st)
+    g2.set_clock()
+    g2.step(n)
+    sg = g2.get_state()
+    plain = samsim_amd.hip_solver(cfg, ncol)
+    plain.set_forcing(*sheba_forcing(), dT, ps)
+    plain.set_state(st)
+    plain.set_clock()
+    plain.step(n)
+    sp = plain.get_state()
+    for name in ("H_abs", "S_abs", "m", "thick", "T"):
+        assert np.array_equal(sp.arr(name)[:, 0], sg.arr(name)[:, 0]), name
+    with pytest.raises(samsim_amd.SamsimError) as e:
+        cfg2, _ = tcs.testcase2(4)
+        samsim_amd.hip_solver(cfg2, 4).set_ocean(None, np.full(4, 30.0))
+    assert e.value.code == -2

@@ -92,4 +92,5 @@ def test_fortran_host_column_ranges(tmp_path):
         assert np.array_equal(lay[:9], whole[0][:9, :, c0:c0 + 96])
         assert np.array_equal(scal, whole[1][:, c0:c0 + 96])
         assert np.array_equal(na, whole[2][c0:c0 + 96])
-    assert len(np.unique(whole[1][0])) > 96     # m_snow differs from column to column
+    from samsim_amd.capi import S
+    assert len(np.unique(whole[1][S["T2m"]])) > 96     # the perturbed air temperature differs from column to column

@@ -490,3 +490,31 @@ def test_function_level_vectors():
         arrs = [np.concatenate([[0.0], row[12 * i:12 * i + 12]]) for i in range(4)]  # 1-based
         fb = lib.oracle_func_freeboard(12, *[a.ctypes.data_as(C.POINTER(d)) for a in arrs], row[48], int(row[49]))
         assert fb == row[50], (fb, row[50])
+
+
+def test_per_column_ocean_leaves_the_reference_column_alone():
+    """samsim_set_ocean (second half): a column with zero heat-flux offset and cfg.S_bu_bottom is the
+    reference's column bit for bit (first 70 output days of testcase 4 against the reference's records); its neighbours, under
+    a warmer / fresher ocean, grow differently"""
+    ref = golden("tc4_ref_fullprec.npz")
+    cfg, st = tcs.testcase4(3)
+    o = oracle_solver(cfg, 3)
+    o.set_forcing(*sheba_forcing())
+    o.set_ocean(np.array([0.0, 6.0, -3.0]), np.array([cfg.S_bu_bottom, 30.0, 36.0]))
+    o.set_state(st)
+    o.set_clock()
+    for day in range(1, 71):
+        out = o.run_to_output()
+        i = day - 1
+        assert out.step == ref["all_step"][i] and out.n_active[0] == ref["all_N_active"][i]
+        for n, rn in SCAL_MAP.items():
+            assert out.sc(n)[0] == ref["all_s_" + rn][i], f"day {day}: scalar {n}"
+    s = o.get_state()
+    assert s.sc("fl_q_bottom")[1] - s.sc("fl_q_bottom")[0] == pytest.approx(6.0, abs=1e-12)
+    assert s.sc("S_bu_bottom")[1] == 30.0 and s.sc("S_bu_bottom")[2] == 36.0
+    thick = [s.arr("thick")[: s.n_active[c], c].sum() for c in range(3)]
+    assert thick[1] < thick[0] < thick[2]        # more oceanic heat -> thinner ice, less -> thicker
+    cfg2, _ = tcs.testcase2(1)
+    o2 = oracle_solver(cfg2, 1)
+    with pytest.raises(Exception):
+        o2.set_ocean(None, np.array([30.0]))     # tank_flag 2: the tank budget owns S_bu_bottom
