@@ -105,6 +105,31 @@ def upload_tiled(solver, st, ncol, col0, chunk=65536):
         c0 += n
 
 
+def host_cores():
+    """CPU cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a one-GPU box shows all 256
+    hardware threads in the mask but grants a 16-core share)"""
+    n = len(os.sched_getaffinity(0))
+    src = "len(os.sched_getaffinity(0))"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, src = q, f"cgroup quota {path} ({quota}/{int(period)}), affinity mask {len(os.sched_getaffinity(0))}"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, src
+
+
 def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
     """oracle (C port of the reference algorithm) on a bounded sample of the same workload: all cores of this process's
     affinity mask (columns over OpenMP threads), then one core"""
@@ -128,14 +153,15 @@ def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
         o.close()
         return ncol * nsteps / dt, nsteps, dt
 
-    cores = len(os.sched_getaffinity(0))
+    cores, cores_source = host_cores()
     v_all, n_all, t_all = run(cores, 4 * cores, target_s)
     v_one, n_one, t_one = run(1, 4, 0.5 * target_s)
     return {"value": v_all, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{4 * cores} columns x {n_all} steps of the same workload on {cores} OpenMP threads ({t_all:.1f} s); "
                       f"one core: 4 columns x {n_one} steps ({t_one:.1f} s)",
-            "cores_source": "len(os.sched_getaffinity(0))",
+            "cores_source": cores_source,
             "one_core": {"value": v_one, "unit": "column-timesteps/s", "cores": 1},
+            "parallel_speedup_measured": v_all / v_one,
             "calibration_vs_flang": CALIBRATION_VS_FLANG,
             "calibration_note": "this port runs at 0.90x the flang -O2 build of the reference itself (same core, testcase 4, "
                                 "first 3.0e6 steps; DESIGN.md section 6)"}

@@ -171,8 +171,9 @@ typedef unsigned long long lu64;
 // LDS-resident per-column scalars: slot s of lane l is word s*SAMSIM_BLOCK + l of the block's array
 enum lds_slot {
   LD_grav_drain = 0, LD_grav_salt, LD_grav_temp, LD_melt_out1, LD_melt_out2, LD_melt_out3, LD_melt_err,
-  LD_freeboard, LD_T_freeze, LD_dT2m, LD_precip_scale, LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
-  LD_T_top_rad,   // per-step hand-over, not a slot of the scalar block
+  LD_freeboard, LD_T_freeze, LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
+  LD_T_top, LD_fl_Q_snow, LD_melt_thick,   // state that only the code between the sweeps touches
+  LD_fl_Q1,                                // fl_Q(1) of this step (surface balance -> top-layer block, melt film): not a slot of the scalar block
   LD_NSLOT
 };
 #define CL(f) c.ld[LD_##f * SAMSIM_BLOCK]
@@ -197,7 +198,7 @@ struct Col {
   long long step;  // completed steps; i = step + 1
   // per-column scalars (enum samsim_scalar)
   double m_snow, H_abs_snow, S_abs_snow, thick_snow, psi_s_snow, psi_l_snow, psi_g_snow, T_snow, phi_s;
-  double T_top, melt_thick, fl_q_bottom, melt_thick_snow, fl_Q_snow;
+  double fl_q_bottom, melt_thick_snow;
   // The other per-column scalars live in LDS for the whole launch (CL(name), one 8-byte word per lane and slot, no bank
   // conflicts): accumulators (grav_*, melt_out*, melt_err), values that are set under conditions and otherwise carried
   // (freeboard, T_freeze), the forcing of the step (T2m, precipitation, albedo, short- and long-wave flux) and the ensemble
@@ -206,7 +207,6 @@ struct Col {
   ldouble *ld;
   double energy_stored, freshwater, total_resist, thickness, bulk_salin;  // vital signs: live at output points only
   // per-step temporaries that cross sweeps
-  double fl_Q1;      // fl_Q(1)
   double frad;       // fl_rad(N_active)
   double flq2;       // fl_Q(2), handed from the down sweep (which applies the conductive update of layers >= 2) to the top-layer block
   double esum;       // SUM(H_abs before - H_abs after the conductive update) over layers >= 2 (energy assert, mo_heat_fluxes.f90:265-310)
@@ -1331,6 +1331,9 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
   c.esum = esum;
 }
 
+template <class K>
+__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x);
+
 // ---------------------------------------------------------------- D: fused down sweep (P2 + P3), top -> bottom
 // One pass instead of two for the common step (not the first, not an output step, no thin-snow coupling, no flooding):
 // per layer j   A(j) expulsion_flux + mass_transfer + S_bu refresh          (mo_mass.f90:112-136, 53-96; mo_grotz.f90:333)
@@ -1341,13 +1344,16 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
 // j-1, j, so the interleaving computes the same values.  S_br(j) and S_br(j+1) of the first sweep are recomputed from
 // T and the pre-expulsion S_abs/m (bit-identical), which needs the raw loads of layer j+1 one iteration early.
 template <class K>
-__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_psi) {
+// store_default: whether the volume fractions of layers >= 3 are stored when the sweep does not decide itself; decide_psi: it
+// decides after layer 2 (see there), storing them anyway under store_default; surface_done: the sweep evaluated the surface balance
+__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_default, bool decide_psi, bool &surface_done) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
   const double dt = g.dt;
   double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300, buoy_g = 0.0;
   int stop_layer = 0;
+  bool store_psi = true;                 // layers 1 and 2 always; the others as decided after layer 2 (below)
   // conductive heat fluxes (sub_heat_fluxes, mo_heat_fluxes.f90:272-285): see C(j-1) below
   double hr_up = 0.0, flq_up = 0.0;      // half resistance thick/(2k) of layer j-1, fl_Q(j-1)
   double esum = 0.0;                     // SUM(H_abs before - after) of the conductive update, for the energy assert
@@ -1359,7 +1365,6 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // 4 waves/SIMD spills inside the loop: 93).
   struct Ld { double T, S_abs, m, H_abs, thick, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
-  unsigned long long rbits = x.rflag[0];   // row flags of rows 1..64; the next word is fetched when j crosses into it
 #if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
   const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
@@ -1375,8 +1380,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
 #else
     r.thick = LAY(SAMSIM_A_THICK, j);
 #endif
-    if (((j - 1) & 63) == 0 && j > 1) rbits = x.rflag[(j - 1) >> 6];
-    r.ray = (j <= Na - 1 && (j == 1 || c.ray_all || ((rbits >> ((j - 1) & 63)) & 1ull) != 0ull)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
+    // (the row flags are read from LDS at every layer: a word kept across iterations is one more value the allocator spills,
+    // and a scratch reload drains every outstanding request of the sweep)
+    r.ray = (j <= Na - 1 && ray_row_valid(c, x, j)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
     return r;
   };
   auto finish = [&](const Ld &l) -> Raw {
@@ -1517,11 +1523,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     ST_MARK(ST_D_B);
   };
   const int jmax = wave_max(Na);
-  for (int j = 1; j < jmax; ++j) {                     // the interior layers j < N_active
-    ISA_MARK("D_ITER_BEGIN");
-    ST_MARK(ST_DFUSED);
-    if (j >= Na) continue;
-    ST_COUNT(CT_DOWN_TRIPS, 1);
+  auto advance = [&](const int j) {                    // the operands of layer j+1 become current, those of layer j+2 (j+3) are requested
     raw_n = finish(ahead);
 #if SAMSIM_DAHEAD >= 3
     ahead = ahead2;
@@ -1529,6 +1531,42 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
 #else
     ahead = load_ld(j + 2 <= N ? j + 2 : N);
 #endif
+  };
+  // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
+  if (1 < Na) { advance(1); layer(1, std::false_type{}); raw = raw_n; }
+  if (2 < Na) { advance(2); layer(2, std::false_type{}); raw = raw_n; }
+  // ---- Who reads the psi_s / psi_l / psi_g rows of the layers below?  The vital signs at the next output point and a get_state
+  // after the launch (force_psi), and -- when the surface melts or the snow releases melt water -- func_freeboard and flush3
+  // (mo_grotz.f90:636,670,717-725).  With N_active >= 3 layer 1 is complete by now (its return-flow transfer C(1) ran with
+  // layer 2), and everything those late readers' conditions depend on can be evaluated exactly: the surface balance
+  // (sub_heat_fluxes' first part reads layer 1, the snow and the forcing, none of which the rest of this sweep touches), hence
+  // T_top, fl_Q(1) and fl_Q_snow; the freezing point of layer 1 (S_abs(1), m(1) stay as they are unless wet snow adds slush);
+  // the snow's enthalpy after the heat fluxes, hence whether the second snow_thermo of the step can find it wet.  The rows are
+  // skipped only when none of the conditions can hold, so a late reader never meets a column without them (they still
+  // check -- code 9001 -- but the check cannot fire; tests/test_gpu_parity.py drives 4 096 columns through a melt season on it).
+  if (decide_psi && Na >= 3) {
+    surface_flux<K>(c, x);
+    surface_done = true;
+    const double thick_min = g.thick_min;
+    const double Tf = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
+    bool snow_wet = false;
+    if (c.thick_snow > 0.0) {
+      // snow_thermo finds liquid water iff H_abs_snow / m_snow > -latent_heat (getT's fresh branch); the up sweep adds
+      // (fl_Q(1) - fl_Q_snow)*dt to a snow cover thicker than thick_min (thinner ones take the unfused path: never here)
+      const double H_new = c.H_abs_snow + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
+      snow_wet = !(c.thick_snow >= thick_min) || !(H_new / c.m_snow <= -latent_heat);
+    }
+    store_psi = store_default || LAY(SAMSIM_A_PSI_S, 1) < psi_s_top_min || CL(T_top) >= Tf || snow_wet || c.melt_thick_snow > 0.0;
+  } else {
+    store_psi = store_default || decide_psi;   // (a deciding sweep over fewer than three layers has nothing left to skip)
+  }
+  c.psi_full = store_psi;
+  for (int j = 3; j < jmax; ++j) {                     // the interior layers 3 <= j < N_active
+    ISA_MARK("D_ITER_BEGIN");
+    ST_MARK(ST_DFUSED);
+    if (j >= Na) continue;
+    ST_COUNT(CT_DOWN_TRIPS, 1);
+    advance(j);
     layer(j, std::false_type{});
     raw = raw_n;
     ISA_MARK("D_ITER_END");
@@ -1614,28 +1652,26 @@ __device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, 
   return temp1;
 }
 
-// T_top_rad: the radiative surface temperature when the caller has formed it already this step (the fused path evaluates it
-// before the down sweep to decide what to store; same inputs, same value), else pass have_rad = false
 template <class K>
-__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x, bool have_rad = false, double T_top_rad = 0.0) {
+__device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1), psi_l1 = LAY(SAMSIM_A_PSI_L, 1), psi_g1 = LAY(SAMSIM_A_PSI_G, 1);
   const double thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   const double k1 = psi_s1 * k_s + psi_l1 * k_l + psi_g1 * 0.0;
   if (CFG(boundflux_flag) == 1) {  // cooling plate, mo_heat_fluxes.f90:77-87
-    double fl = (T1 - c.T_top) / (thick1 / (2.0 * k1));
+    double fl = (T1 - CL(T_top)) / (thick1 / (2.0 * k1));
     if (fabs(fl) > g.max_flux_plate) fl = fl / fabs(fl) * g.max_flux_plate;
-    c.fl_Q1 = fl;
+    CL(fl_Q1) = fl;
     return;
   }
   if (K::general && CFG(boundflux_flag) == 3) {  // lab air temperature, mo_heat_fluxes.f90:202-219 (lab_snow_flag 0)
     CL(T_freeze) = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
-    c.T_top = T1;
-    c.fl_Q1 = g.alpha_flux_instable * (c.T_top - CL(T2m));
-    if (c.fl_Q1 < 0.0) {
-      c.T_top = dmax(CL(T_freeze), T1);
-      c.fl_Q1 = g.alpha_flux_stable * (c.T_top - CL(T2m));
+    CL(T_top) = T1;
+    CL(fl_Q1) = g.alpha_flux_instable * (CL(T_top) - CL(T2m));
+    if (CL(fl_Q1) < 0.0) {
+      CL(T_top) = dmax(CL(T_freeze), T1);
+      CL(fl_Q1) = g.alpha_flux_stable * (CL(T_top) - CL(T2m));
     }
     return;
   }
@@ -1645,7 +1681,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x, bool have_rad
   const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
   double temp1;
-  c.T_top = have_rad ? T_top_rad : radiative_T_top(c, fl_rest, T1, thick_min);
+  CL(T_top) = radiative_T_top(c, fl_rest, T1, thick_min);
 
   if (c.thick_snow >= thick_min / 100.0) CL(T_freeze) = 0.0;
   else CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
@@ -1653,23 +1689,23 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x, bool have_rad
   const double k_snow = (c.thick_snow >= thick_min / 100.0) ? func_k_snow(c.m_snow, c.thick_snow) : 0.0;
   // sub_fl_Q_snow, mo_snow.f90:498-518
   const double flq_snow_ice = (T1 - c.T_snow) / (c.thick_snow / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
-  if (c.T_top > CL(T_freeze) && Na > 1) {
+  if (CL(T_top) > CL(T_freeze) && Na > 1) {
     temp1 = emi * sigma * pow(CL(T_freeze) + zeroK, 4.0) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
-    if (c.thick_snow >= thick_min) { c.fl_Q_snow = temp1; c.fl_Q1 = flq_snow_ice; }
-    else if (c.thick_snow >= thick_min / 100.0) { c.fl_Q_snow = temp1; c.fl_Q1 = 0.0; }
-    else c.fl_Q1 = temp1;
-    c.T_top = CL(T_freeze);
+    if (c.thick_snow >= thick_min) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = flq_snow_ice; }
+    else if (c.thick_snow >= thick_min / 100.0) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = 0.0; }
+    else CL(fl_Q1) = temp1;
+    CL(T_top) = CL(T_freeze);
   } else {
     if (c.thick_snow >= thick_min) {
-      c.fl_Q1 = flq_snow_ice;
-      c.fl_Q_snow = (c.T_snow - c.T_top) / (c.thick_snow / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
+      CL(fl_Q1) = flq_snow_ice;
+      CL(fl_Q_snow) = (c.T_snow - CL(T_top)) / (c.thick_snow / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
     } else if (c.thick_snow > thick_min / 100.0 && c.thick_snow < thick_min) {
-      c.fl_Q1 = 0.0;
+      CL(fl_Q1) = 0.0;
       // sub_fl_Q_0_snow_thin, mo_snow.f90:466-487
       double k = c.thick_snow / (c.thick_snow + thick1) * k_snow + thick1 / (c.thick_snow + thick1) * k1;
-      c.fl_Q_snow = (c.T_snow - c.T_top) / ((c.thick_snow + thick1) / (2.0 * k));
+      CL(fl_Q_snow) = (c.T_snow - CL(T_top)) / ((c.thick_snow + thick1) / (2.0 * k));
     } else {
-      c.fl_Q1 = (T1 - c.T_top) / (thick1 / (2.0 * k1));
+      CL(fl_Q1) = (T1 - CL(T_top)) / (thick1 / (2.0 * k1));
     }
   }
 }
@@ -1738,17 +1774,17 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       // conductive update of layer 1: fl_Q(2) from the down sweep (fl_q_bottom under a single layer), fl_Q(1) from the surface balance
       const double flq_below = (Na >= 2) ? c.flq2 : c.fl_q_bottom;
       const double H_b = H_abs;
-      H_abs = H_abs + (flq_below - c.fl_Q1) * dt;
+      H_abs = H_abs + (flq_below - CL(fl_Q1)) * dt;
       H_abs = H_abs + c.frad * dt;
       // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
-        c.H_abs_snow = c.H_abs_snow - c.fl_Q_snow * dt;
+        c.H_abs_snow = c.H_abs_snow - CL(fl_Q_snow) * dt;
         LAY(SAMSIM_A_H_ABS, 1) = H_abs;
         snow_coupling<K>(c, x);
         if (c.status) { alive = false; return; }
         H_abs = LAY(SAMSIM_A_H_ABS, 1);
       } else if (c.thick_snow >= thick_min) {
-        c.H_abs_snow = c.H_abs_snow + (c.fl_Q1 - c.fl_Q_snow) * dt;
+        c.H_abs_snow = c.H_abs_snow + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
       }
       esum += H_b - H_abs;   // (after the thin-snow coupling, which moves enthalpy between the snow and layer 1)
       LAY(SAMSIM_A_H_ABS, 1) = H_abs;
@@ -1807,8 +1843,8 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // with the two sums taken as one sum of per-layer differences
   double bal = esum + (H_abs_snow_before - c.H_abs_snow);
   bal = bal + (double)Na * (c.frad * dt);
-  if (thin_snow || c.thick_snow >= thick_min) bal = bal + c.fl_q_bottom * dt - c.fl_Q_snow * dt;
-  else bal = bal + c.fl_q_bottom * dt - c.fl_Q1 * dt;
+  if (thin_snow || c.thick_snow >= thick_min) bal = bal + c.fl_q_bottom * dt - CL(fl_Q_snow) * dt;
+  else bal = bal + c.fl_q_bottom * dt - CL(fl_Q1) * dt;
   if (rc) STOPC(rc, rc_layer);
   if (fabs(bal / dt) > 0.00001) STOPC(431, 0);
 }
@@ -1846,8 +1882,8 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   for (int k = 1; k <= Na; ++k) cnst += LAY(SAMSIM_A_THICK, k);
   cnst = cnst * para_flush_horiz;
   const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
-  c.melt_thick = dmin(c.melt_thick, psi_l1 * thick1);
-  c.melt_thick = dmin(c.melt_thick, g.thick_0 / 3.0);
+  CL(melt_thick) = dmin(CL(melt_thick), psi_l1 * thick1);
+  CL(melt_thick) = dmin(CL(melt_thick), g.thick_0 / 3.0);
 
   // permeability and bottom -> top equivalent resistance R(k) (stored in the V_ex scratch rows)
   const double pfill = (CFG(snow_flush_flag) == 1) ? 0.0 : 1.0;
@@ -1873,9 +1909,9 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     R_below = R;
   }
   const double R1 = R_below;
-  double flush_total = (CL(freeboard) + c.melt_thick) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
-  flush_total = dmin(flush_total, c.melt_thick * rho_l);
-  CL(melt_err) = CL(melt_err) + c.melt_thick - dmin(flush_total / rho_l, c.melt_thick);
+  double flush_total = (CL(freeboard) + CL(melt_thick)) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
+  flush_total = dmin(flush_total, CL(melt_thick) * rho_l);
+  CL(melt_err) = CL(melt_err) + CL(melt_thick) - dmin(flush_total / rho_l, CL(melt_thick));
 
   // top -> bottom: split into vertical / horizontal parts, vertical mass_transfer (fl_m(k+1) = -flush_v(k) <= 0),
   // horizontal loss of every layer goes to layer N_active
@@ -2274,19 +2310,20 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
     OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
     OUT(SAMSIM_S_PSI_G_SNOW, c.psi_g_snow); OUT(SAMSIM_S_T_SNOW, c.T_snow); OUT(SAMSIM_S_PHI_S, c.phi_s);
-    OUT(SAMSIM_S_T_TOP, c.T_top); OUT(SAMSIM_S_MELT_THICK, c.melt_thick); OUT(SAMSIM_S_T2M, CL(T2m));
+    OUT(SAMSIM_S_T_TOP, CL(T_top)); OUT(SAMSIM_S_MELT_THICK, CL(melt_thick)); OUT(SAMSIM_S_T2M, CL(T2m));
     OUT(SAMSIM_S_LIQUID_PRECIP, CL(liquid_precip)); OUT(SAMSIM_S_SOLID_PRECIP, CL(solid_precip)); OUT(SAMSIM_S_FL_Q_BOTTOM, c.fl_q_bottom);
     OUT(SAMSIM_S_GRAV_DRAIN, CL(grav_drain)); OUT(SAMSIM_S_GRAV_SALT, CL(grav_salt)); OUT(SAMSIM_S_GRAV_TEMP, CL(grav_temp));
     OUT(SAMSIM_S_MELT_OUT1, CL(melt_out1)); OUT(SAMSIM_S_MELT_OUT2, CL(melt_out2)); OUT(SAMSIM_S_MELT_OUT3, CL(melt_out3));
     OUT(SAMSIM_S_MELT_ERR, CL(melt_err)); OUT(SAMSIM_S_FREEBOARD, CL(freeboard)); OUT(SAMSIM_S_T_FREEZE, CL(T_freeze));
     OUT(SAMSIM_S_ALBEDO, CL(albedo)); OUT(SAMSIM_S_FL_SW, CL(fl_sw)); OUT(SAMSIM_S_FL_LW, CL(fl_lw));
-    OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, c.fl_Q_snow);
+    OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, CL(fl_Q_snow));
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
     OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? CL(fl_lw) + 0.0 + 0.0
                                                                         : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
     OUT(SAMSIM_S_S_BU_BOTTOM, x.S_bu_bottom);
-    OUT(SAMSIM_S_DT2M, CL(dT2m)); OUT(SAMSIM_S_PRECIP_SCALE, CL(precip_scale));
+    OUT(SAMSIM_S_DT2M, x.scal[(size_t)SAMSIM_S_DT2M * c.ncol + c.col]);
+    OUT(SAMSIM_S_PRECIP_SCALE, x.scal[(size_t)SAMSIM_S_PRECIP_SCALE * c.ncol + c.col]);
 #undef OUT
     x.out_n_active[oc] = c.Na;
     if (HAS_BGC) {
@@ -2341,13 +2378,13 @@ __device__ RARE void prescribe_salinity(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void flush4(Col &c, const Ctx &x) {
   const int Na = c.Na;
-  const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1), melt = c.melt_thick;
+  const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1), melt = CL(melt_thick);
   double S1 = LAY(SAMSIM_A_S_ABS, 1);
   LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - melt * rho_l * c_l * T1;
   S1 = S1 - melt * rho_l * S_br_clamped(x.salt, T1, S1 / m1);
   LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - melt;
   LAY(SAMSIM_A_M, 1) = m1 - melt * rho_l;
-  c.melt_thick = 0.0;
+  CL(melt_thick) = 0.0;
   double above = LAY(SAMSIM_A_PSI_L, 1);
   for (int k = 2; k <= Na; ++k) {
     const double here = LAY(SAMSIM_A_PSI_L, k);
@@ -2366,7 +2403,7 @@ template <class K>
 __device__ __forceinline__ void testcase_scalars(Col &c, const Ctx &x, const samsim_config &g, double time) {
   if (CFG(testcase) == 1) {  // sub_test1, mo_testcase_specifics.f90:42-89
     for (int n = 1; n <= 20; ++n) {
-      if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { c.T_top = (n & 1) ? -10.0 : -5.0; break; }
+      if (fabs(time - (double)((float)(12 * n) * 3600.0f)) < (double)0.01f) { CL(T_top) = (n & 1) ? -10.0 : -5.0; break; }
     }
   } else if (K::general && CFG(testcase) == 3) {  // sub_test3, :172-187
     CL(liquid_precip) = 0.0;
@@ -2499,8 +2536,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       CL(T2m) = (1.0 - temp) * x.f_T2m[x.soff + tc - 2] + temp * x.f_T2m[x.soff + tc - 1];
       CL(liquid_precip) = (1.0 - temp) * x.f_precip[x.soff + tc - 2] + temp * x.f_precip[x.soff + tc - 1];
     }
-    CL(T2m) = CL(T2m) + CL(dT2m);
-    CL(liquid_precip) = CL(liquid_precip) * CL(precip_scale);
+    // the column's perturbation (samsim_set_forcing): two words of the scalar block, read where they are used
+    CL(T2m) = CL(T2m) + x.scal[(size_t)SAMSIM_S_DT2M * c.ncol + c.col];
+    CL(liquid_precip) = CL(liquid_precip) * x.scal[(size_t)SAMSIM_S_PRECIP_SCALE * c.ncol + c.col];
   }
 
   c.bgc_flood = 0.0; c.bgc_grav = false;
@@ -2531,7 +2569,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   ST_MARK(ST_PRO);
   ST_COUNT(CT_WAVESTEPS, 1);
   ST_COUNT(CT_LANES, (unsigned long long)__popcll(__ballot(1)));
-  bool have_rad = false;   // the radiative surface temperature of this step has been formed already (CL(T_top_rad))
+  bool surface_done = false;   // the fused down sweep has evaluated the surface balance already
   if (fused) {
     ST_COUNT(CT_FUSED, 1);
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
@@ -2539,32 +2577,19 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     testcase_scalars<K>(c, x, g, time);
     const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
-    // Who reads the psi_s / psi_l / psi_g arrays this sweep would store?  The vital signs at the next output point, a
-    // get_state after the launch, and -- when the surface melts or the snow releases melt water -- func_freeboard and
-    // flush3 (mo_grotz.f90:636,670,717-725).  Whether those run is decided after the sweep; it is predicted here with
-    // wide margins (surface within 1 K of melting, top layer within 0.05 of the solid-fraction threshold, snow warmer
-    // than -8 C or already wet) and the late readers stop the column (code 9001) should the prediction ever have been
-    // wrong.  Everything else (layer 1 itself, the up sweep's conductivities) is handed over separately.
-    bool store_psi = true;
+    // The volume fractions of layers >= 3 are only stored where something reads them (see sweep_down_fused): always through the
+    // run-time-flag instantiation; with melt-water flushing (flush_flag 5 on the radiative surface) the sweep decides from the
+    // finished top layer; without it (flush_flag 1) only the vital signs at the next output point and a get_state after the
+    // launch read them
+    bool store_default = true, decide_psi = false;
 #ifndef SAMSIM_STORE_PSI_ALWAYS
-    if (K::fixed && K::boundflux_flag == 2 && K::flush_flag == 5) {
-      const double th1 = LAY(SAMSIM_A_THICK, 1), m1 = LAY(SAMSIM_A_M, 1);
-      const Expelled e1 = expulsion(LAY(SAMSIM_A_PHI, 1), th1, m1);
-      const double T_fr = (c.thick_snow >= g.thick_min / 100.0) ? 0.0 : func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / m1, CFG(salt_flag), x.tf_c3);
-      const double T_top_est = radiative_T_top(c, CL(fl_lw) + 0.0 + 0.0, LAY(SAMSIM_A_T, 1), g.thick_min);
-      have_rad = true;
-      CL(T_top_rad) = T_top_est;   // surface_flux forms the same value from the same inputs: handed on through LDS
-      store_psi = next_out || last_step || e1.psi_s < psi_s_top_min + 0.05 || T_top_est >= T_fr - 1.0 ||
-                  (c.thick_snow > 0.0 && (c.T_snow > -8.0 || c.melt_thick_snow > 0.0));
-    }
+    if (K::fixed && K::boundflux_flag == 2 && K::flush_flag == 5) { store_default = next_out || last_step; decide_psi = true; }
+    if (K::fixed && K::flush_flag == 1) store_default = next_out || last_step;
 #endif
-    // without melt-water flushing (flush_flag 1) nothing on the fused path reads them but the vital signs and get_state
-    if (K::fixed && K::flush_flag == 1) store_psi = next_out || last_step;
-    c.psi_full = store_psi;
     // fl_rad(N_active) enters the conductive update of every layer (mo_heat_fluxes.f90:282-285), which the down sweep applies as
     // it goes: the Beer-law product over the layer thicknesses (a pass over one array) comes first
     if (do_beer) sweep_beer<K>(c, x, beer0);
-    sweep_down_fused<K>(c, x, store_psi);
+    sweep_down_fused<K>(c, x, store_default, decide_psi, surface_done);
     ST_MARK(ST_DFUSED);
     if (c.status) return;
   } else {
@@ -2589,7 +2614,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   }
 
   // heat fluxes + second thermodynamic sweep (mo_grotz.f90:584-598) + first sweep of the next step for layers >= 2
-  surface_flux<K>(c, x, have_rad, have_rad ? (double)CL(T_top_rad) : 0.0);
+  if (!surface_done) surface_flux<K>(c, x);
   ST_MARK(ST_SURF);
   sweep_up_fused<K>(c, x, col, next_out, next_out || last_step);
   ST_MARK(ST_UP);
@@ -2606,9 +2631,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   if (Na > 1 && CFG(flush_flag) > 2 && (CFG(boundflux_flag) == 2 || (K::general && CFG(boundflux_flag) == 3))) {
     // boundflux_flag 3 (:649-663) runs the same block on the air temperature instead of the surface temperature
     const bool lab = K::general && CFG(boundflux_flag) == 3;
-    const double T_surf = lab ? CL(T2m) : c.T_top;
+    const double T_surf = lab ? CL(T2m) : CL(T_top);
     CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
-    c.melt_thick = 0.0;
+    CL(melt_thick) = 0.0;
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || T_surf >= CL(T_freeze)) {
@@ -2618,15 +2643,17 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       if (CL(freeboard) > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
-        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), CL(T_freeze), T_surf, c.fl_Q1,
-                       c.thick_snow, g.dt, c.melt_thick, thick1, g.thick_min);
-        if (lab) c.melt_thick = dmax(c.melt_thick, 0.0);
-        if (c.thick_snow >= g.thick_min / 100.0 && c.melt_thick > 0.00000000001 && c.melt_thick_snow == 0.0) {
+        double melt_thick = 0.0;
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), CL(T_freeze), T_surf, CL(fl_Q1),
+                       c.thick_snow, g.dt, melt_thick, thick1, g.thick_min);
+        CL(melt_thick) = melt_thick;
+        if (lab) CL(melt_thick) = dmax(CL(melt_thick), 0.0);
+        if (c.thick_snow >= g.thick_min / 100.0 && CL(melt_thick) > 0.00000000001 && c.melt_thick_snow == 0.0) {
           // sub_melt_snow, mo_functions.f90:443-474
           double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1);
-          const double shift = 1.0 / dmax(c.psi_g_snow, 0.01) * c.melt_thick;
+          const double shift = 1.0 / dmax(c.psi_g_snow, 0.01) * CL(melt_thick);
           if (shift >= c.thick_snow) {
-            c.melt_thick = c.melt_thick - c.thick_snow * c.psi_g_snow;
+            CL(melt_thick) = CL(melt_thick) - c.thick_snow * c.psi_g_snow;
             H_abs = H_abs + c.H_abs_snow;
             m = m + c.m_snow;
             thick1 = thick1 + (1.0 - c.psi_g_snow) * c.thick_snow;
@@ -2636,9 +2663,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
             c.H_abs_snow = c.H_abs_snow - shift / c.thick_snow * c.H_abs_snow;
             m = m + shift / c.thick_snow * c.m_snow;
             c.m_snow = c.m_snow - shift / c.thick_snow * c.m_snow;
-            thick1 = thick1 + shift - c.melt_thick;
+            thick1 = thick1 + shift - CL(melt_thick);
             c.thick_snow = c.thick_snow - shift;
-            c.melt_thick = 0.0;
+            CL(melt_thick) = 0.0;
           }
           LAY(SAMSIM_A_H_ABS, 1) = H_abs;
           LAY(SAMSIM_A_M, 1) = m;
@@ -2652,12 +2679,12 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // flushing, mo_grotz.f90:670-737
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
-                               c.melt_thick + c.melt_thick_snow > 0.000000000001);
+                               CL(melt_thick) + c.melt_thick_snow > 0.000000000001);
   if (flush_possible && !c.psi_full) STOPC(9001, 0);
   if (flush_possible && !fb_valid) CL(freeboard) = func_freeboard<K>(c, x);
-  CL(melt_out1) = CL(melt_out1) + c.melt_thick;
+  CL(melt_out1) = CL(melt_out1) + CL(melt_thick);
   CL(melt_out2) = CL(melt_out2) + c.melt_thick_snow;
-  c.melt_thick = c.melt_thick + c.melt_thick_snow;
+  CL(melt_thick) = CL(melt_thick) + c.melt_thick_snow;
   if (c.melt_thick_snow > 0.0) {
     const double mts = c.melt_thick_snow;
     double H1 = LAY(SAMSIM_A_H_ABS, 1), S1 = LAY(SAMSIM_A_S_ABS, 1), m1 = LAY(SAMSIM_A_M, 1);
@@ -2669,13 +2696,13 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     LAY(SAMSIM_A_S_BU, 1) = S1 / m1;
   }
   if (flush_possible && CL(freeboard) > 0.001) {
-    if (c.melt_thick > 0.000000000001) {
+    if (CL(melt_thick) > 0.000000000001) {
       if (K::general && CFG(flush_flag) == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
         const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
-        LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - c.melt_thick * rho_l * c_l * T1;
-        LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (c.melt_thick * rho_l) / m1);
-        LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - c.melt_thick;
-        LAY(SAMSIM_A_M, 1) = m1 - c.melt_thick * rho_l;
+        LAY(SAMSIM_A_H_ABS, 1) = LAY(SAMSIM_A_H_ABS, 1) - CL(melt_thick) * rho_l * c_l * T1;
+        LAY(SAMSIM_A_S_ABS, 1) = LAY(SAMSIM_A_S_ABS, 1) * (1.0 - (CL(melt_thick) * rho_l) / m1);
+        LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - CL(melt_thick);
+        LAY(SAMSIM_A_M, 1) = m1 - CL(melt_thick) * rho_l;
       } else if (K::general && CFG(flush_flag) == 6) {  // :729-733
         if (c.thick_snow < g.thick_0) {
           flush4<K>(c, x);
@@ -2785,7 +2812,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.status = status[col];
   c.err_layer = err_layer[col];
   c.err_step = err_step[col];
-  c.fl_Q1 = 0.0; c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
+  c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
   c.spec = (gdouble *)spec;
   const size_t nc = (size_t)p.ncol;
@@ -2794,8 +2821,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SLOAD(m_snow, SAMSIM_S_M_SNOW); SLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SLOAD(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SLOAD(thick_snow, SAMSIM_S_THICK_SNOW); SLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SLOAD(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
   SLOAD(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SLOAD(T_snow, SAMSIM_S_T_SNOW); SLOAD(phi_s, SAMSIM_S_PHI_S);
-  SLOAD(T_top, SAMSIM_S_T_TOP); SLOAD(melt_thick, SAMSIM_S_MELT_THICK); SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
-  SLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SLOAD(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
+  SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM); SLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
 #undef SLOAD
   // row flags of the Rayleigh-number array (Ctx::rflag): at the start of a launch every row is valid (the last up sweep of a
   // launch stores all rows, as does samsim_set_state's full first sweep)
@@ -2809,7 +2835,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   LLOAD(grav_drain, SAMSIM_S_GRAV_DRAIN); LLOAD(grav_salt, SAMSIM_S_GRAV_SALT); LLOAD(grav_temp, SAMSIM_S_GRAV_TEMP);
   LLOAD(melt_out1, SAMSIM_S_MELT_OUT1); LLOAD(melt_out2, SAMSIM_S_MELT_OUT2); LLOAD(melt_out3, SAMSIM_S_MELT_OUT3);
   LLOAD(melt_err, SAMSIM_S_MELT_ERR); LLOAD(freeboard, SAMSIM_S_FREEBOARD); LLOAD(T_freeze, SAMSIM_S_T_FREEZE);
-  LLOAD(dT2m, SAMSIM_S_DT2M); LLOAD(precip_scale, SAMSIM_S_PRECIP_SCALE);
+  LLOAD(T_top, SAMSIM_S_T_TOP); LLOAD(fl_Q_snow, SAMSIM_S_FL_Q_SNOW); LLOAD(melt_thick, SAMSIM_S_MELT_THICK);
+  CL(fl_Q1) = 0.0;
   LLOAD(albedo, SAMSIM_S_ALBEDO); LLOAD(fl_sw, SAMSIM_S_FL_SW); LLOAD(fl_lw, SAMSIM_S_FL_LW);
   LLOAD(T2m, SAMSIM_S_T2M); LLOAD(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LLOAD(solid_precip, SAMSIM_S_SOLID_PRECIP);
 #undef LLOAD
@@ -2852,8 +2879,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   SSTORE(m_snow, SAMSIM_S_M_SNOW); SSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SSTORE(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
   SSTORE(thick_snow, SAMSIM_S_THICK_SNOW); SSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SSTORE(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
   SSTORE(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SSTORE(T_snow, SAMSIM_S_T_SNOW); SSTORE(phi_s, SAMSIM_S_PHI_S);
-  SSTORE(T_top, SAMSIM_S_T_TOP); SSTORE(melt_thick, SAMSIM_S_MELT_THICK); SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
-  SSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW); SSTORE(fl_Q_snow, SAMSIM_S_FL_Q_SNOW);
+  SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM); SSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
 #undef SSTORE
 #define LSTORE(field, idx) sc[(size_t)(idx) * nc] = CL(field)
   LSTORE(grav_drain, SAMSIM_S_GRAV_DRAIN); LSTORE(grav_salt, SAMSIM_S_GRAV_SALT); LSTORE(grav_temp, SAMSIM_S_GRAV_TEMP);
@@ -2861,6 +2887,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   LSTORE(melt_err, SAMSIM_S_MELT_ERR); LSTORE(freeboard, SAMSIM_S_FREEBOARD); LSTORE(T_freeze, SAMSIM_S_T_FREEZE);
   LSTORE(albedo, SAMSIM_S_ALBEDO); LSTORE(fl_sw, SAMSIM_S_FL_SW); LSTORE(fl_lw, SAMSIM_S_FL_LW);
   LSTORE(T2m, SAMSIM_S_T2M); LSTORE(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LSTORE(solid_precip, SAMSIM_S_SOLID_PRECIP);
+  LSTORE(T_top, SAMSIM_S_T_TOP); LSTORE(fl_Q_snow, SAMSIM_S_FL_Q_SNOW); LSTORE(melt_thick, SAMSIM_S_MELT_THICK);
 #undef LSTORE
   sc[(size_t)SAMSIM_S_S_BU_BOTTOM * nc] = x.S_bu_bottom;
   // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112

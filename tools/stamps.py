@@ -29,9 +29,12 @@ def main():
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--workload", default="sheba")
     ap.add_argument("--sites", type=int, default=1)
+    ap.add_argument("--fixture", default=None, help="stage fixture to start from (e.g. sheba_ensemble_80_day360.npz)")
     args = ap.parse_args()
     import samsim_amd
     cfg, st, pert, clock, forcing, wname, _ = bench.workload(args)
+    if args.fixture:
+        _, st, clock, _ = bench.load_ensemble(args.fixture)
     g = samsim_amd.hip_solver(cfg, args.ncol, device=0)
     if forcing is not None:
         g.set_forcing(*forcing, bench.tile(pert[0], args.ncol, 0), bench.tile(pert[1], args.ncol, 0))
