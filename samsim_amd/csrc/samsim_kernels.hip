@@ -290,8 +290,30 @@ __device__ __forceinline__ int wave_max(int v) {
 __device__ __forceinline__ bool wave_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
 
 #include "samsim_div.h"
+// MAX / MIN of the reference as one v_max_f64 / v_min_f64 each.  `a > b ? a : b` compiles to a compare and two 32-bit selects
+// (the C semantics for NaN and signed zeros differ from the instruction's), and every vector instruction costs the same four
+// cycles: the sweeps clamp some twenty times per layer-cell.  For ordered operands the value is the same (max(-0, +0) may come out
+// as +0 instead of -0: equal numbers); a NaN operand loses against a number in both forms where the number is the constant.
+// SAMSIM_MINMAX_ASM 0 = the ternaries.
+#ifndef SAMSIM_MINMAX_ASM
+#define SAMSIM_MINMAX_ASM 1
+#endif
+#if SAMSIM_MINMAX_ASM && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double dmax(double a, double b) {
+  double r;
+  if (__builtin_constant_p(b) && b == 0.0) asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+  else asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double dmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#else
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+#endif
 // S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594
 __device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
 #if SAMSIM_FAST_DIV
@@ -1363,10 +1385,14 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // layer below is needed one layer early), which puts a full iteration of work between request and use.  Measured on the
   // default bench: loads at use 82.3 ms per launch, one layer ahead 76.0, two ahead at 3 waves/SIMD 73.8 (two ahead at
   // 4 waves/SIMD spills inside the loop: 93).
-  struct Ld { double T, S_abs, m, H_abs, thick, ray; };
+  // Operands run two iterations ahead of the arithmetic with two request buffers and ONE finished layer: the operands of layer
+  // j+2 are requested at the top of iteration j and turned into `raw` at the END of iteration j+1.  (Round 1 and the first half of
+  // round 2 finished layer j+1 at the top of iteration j, because the drainage test of B(j) compares S_br(j) with S_br(j+1): one
+  // iteration of lead, a second finished layer -- 18 registers -- held for the sake of a test that is reached in 3 % of the
+  // layers.  That test now forms S_br(j+1) from the request buffer on demand.)
+  struct Ld { double T, S_abs, m, H_abs, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
 #if SAMSIM_THICK_RULE
-  const bool regular = (c.flags & COLF_REGULAR) != 0;
   const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
 #endif
   auto load_ld = [&](int j) -> Ld {
@@ -1375,22 +1401,27 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     r.S_abs = LAY(SAMSIM_A_S_ABS, j);
     r.m = LAY(SAMSIM_A_M, j);
     r.H_abs = LAY(SAMSIM_A_H_ABS, j);
-#if SAMSIM_THICK_RULE
-    r.thick = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, j);
-#else
-    r.thick = LAY(SAMSIM_A_THICK, j);
-#endif
     // (the row flags are read from LDS at every layer: a word kept across iterations is one more value the allocator spills,
     // and a scratch reload drains every outstanding request of the sweep)
     r.ray = (j <= Na - 1 && ray_row_valid(c, x, j)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
     return r;
   };
-  auto finish = [&](const Ld &l) -> Raw {
+  auto finish = [&](const Ld &l, int j) -> Raw {
     Raw r;
-    r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.thick = l.thick; r.ray = l.ray;
+    r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.ray = l.ray;
+#if SAMSIM_THICK_RULE
+    r.thick = (j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
+#else
+    r.thick = LAY(SAMSIM_A_THICK, j);
+#endif
     per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
+  };
+  auto S_br_below = [&](const Ld &l) -> double {    // S_br of the layer in a request buffer, exactly as finish() will form it
+    double S_bu, H;
+    per_mass(l.S_abs, l.H_abs, l.m, S_bu, H);
+    return S_br_clamped(s, l.T, S_bu);
   };
   // (SA, mA: salt and mass right after A(j).  Their quotient, the refreshed bulk salinity of mo_grotz.f90:333-335, is only
   // read where brine actually moves -- the drainage test of B(j) and the return-flow transfers of C -- so it is formed there:
@@ -1401,12 +1432,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
   // (requests are issued unconditionally, from a clamped row where the layer does not exist -- see sweep_up_fused)
   const int N = c.N;
-  Ld ahead = load_ld(1);
-  Raw raw = finish(ahead), raw_n = raw;
-  ahead = load_ld(2);                                  // nlayer >= 3 (samsim_create)
-#if SAMSIM_DAHEAD >= 3
-  Ld ahead2 = load_ld(3);                              // layer j+2 (ahead = layer j+1): requested two iterations before use
-#endif
+  Raw raw = finish(load_ld(1), 1);
+  Ld ahead = load_ld(2), ahead2 = ahead;               // layers j+1 and j+2 (nlayer >= 3, samsim_create)
   Lay prev = {0, 0, 1, 0, 0, 0, 0};                    // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
   // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
@@ -1472,7 +1499,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     double flup = cum;
     if (!LAST) {
       const double ray = raw.ray;
-      if (ray > ray_crit && S_br > raw_n.S_br) {
+      // S_br(j+1) of the first sweep, from the request buffer of layer j+1 (same operands and operations as finish())
+      if (ray > ray_crit && S_br > S_br_below(ahead)) {
         const double psi_s = ex.psi_s;
         if (psi_s > 0.001 && quot(SA, mA) > 0.1) {  // S_bu of this layer (j < N_active: nothing changed since A)
           ST_COUNT(CT_DRAIN_WAVE, 1);
@@ -1523,18 +1551,11 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     ST_MARK(ST_D_B);
   };
   const int jmax = wave_max(Na);
-  auto advance = [&](const int j) {                    // the operands of layer j+1 become current, those of layer j+2 (j+3) are requested
-    raw_n = finish(ahead);
-#if SAMSIM_DAHEAD >= 3
-    ahead = ahead2;
-    ahead2 = load_ld(j + 3 <= N ? j + 3 : N);
-#else
-    ahead = load_ld(j + 2 <= N ? j + 2 : N);
-#endif
-  };
+  auto request = [&](const int j) { ahead2 = load_ld(j + 2 <= N ? j + 2 : N); };      // top of iteration j: layer j+2
+  auto advance = [&](const int j) { raw = finish(ahead, j + 1); ahead = ahead2; };      // end of iteration j: layer j+1 becomes current
   // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
-  if (1 < Na) { advance(1); layer(1, std::false_type{}); raw = raw_n; }
-  if (2 < Na) { advance(2); layer(2, std::false_type{}); raw = raw_n; }
+  if (1 < Na) { request(1); layer(1, std::false_type{}); advance(1); }
+  if (2 < Na) { request(2); layer(2, std::false_type{}); advance(2); }
   // ---- Who reads the psi_s / psi_l / psi_g rows of the layers below?  The vital signs at the next output point and a get_state
   // after the launch (force_psi), and -- when the surface melts or the snow releases melt water -- func_freeboard and flush3
   // (mo_grotz.f90:636,670,717-725).  With N_active >= 3 layer 1 is complete by now (its return-flow transfer C(1) ran with
@@ -1566,9 +1587,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     ST_MARK(ST_DFUSED);
     if (j >= Na) continue;
     ST_COUNT(CT_DOWN_TRIPS, 1);
-    advance(j);
+    request(j);
     layer(j, std::false_type{});
-    raw = raw_n;
+    advance(j);
     ISA_MARK("D_ITER_END");
   }
   layer(Na, std::true_type{});                         // the bottom layer (this sweep only runs with N_active >= 2)
@@ -2564,7 +2585,11 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
                                c.m_snow > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
-                     !(K::general && CFG(prescribe_flag) == 2);
+                     !(K::general && CFG(prescribe_flag) == 2)
+#if SAMSIM_THICK_RULE
+                     && (c.flags & COLF_REGULAR) != 0   // the fused down sweep takes the thicknesses from the grid rule only
+#endif
+      ;
 
   ST_MARK(ST_PRO);
   ST_COUNT(CT_WAVESTEPS, 1);
