@@ -77,12 +77,12 @@ def test_fortran_host_testcases_3_and_5(tmp_path):
     temperature and thickness profiles follow the reference's full-precision records of the same output points"""
     d3 = tmp_path / "tc3"
     d3.mkdir()
-    out = run_host(d3, "&samsim_run testcase=3, ncol=8, max_steps=126100 /\n")
+    out = run_host(d3, "&samsim_run testcase=3, ncol=8, max_steps=65600 /\n")
     assert "SAMSIM is finished" in out
     ref = golden("tc3_ref_fullprec.npz")
     T, th = load(d3, "T"), load(d3, "thick")
     n = T.shape[0]
-    assert n == 26 and T.shape[1] == 20                      # outputs every 5040 steps + step 1
+    assert n == 14 and T.shape[1] == 20                      # outputs every 5040 steps + step 1
     for i in range(n):
         na = int(ref["N_active"][i])
         assert np.abs(T[i, :na] - ref["a_T"][i, :na]).max() <= 1.5e-3, f"tc3 output {i}"
@@ -90,11 +90,11 @@ def test_fortran_host_testcases_3_and_5(tmp_path):
     assert "atmoflux_flag           1" in (d3 / "output" / "dat_settings.dat").read_text()
     d5 = tmp_path / "tc5"
     d5.mkdir()
-    out = run_host(d5, "&samsim_run testcase=5, ncol=8, max_steps=40000 /\n")
+    out = run_host(d5, "&samsim_run testcase=5, ncol=8, max_steps=21700 /\n")
     ref = golden("tc5_ref_fullprec.npz")
     T = load(d5, "T")
     rows = {int(x): j for j, x in enumerate(ref["index"])}
-    assert T.shape == (38, 100)
+    assert T.shape == (21, 100)
     for i, j in rows.items():
         if i < T.shape[0]:
             na = int(ref["all_N_active"][i])
@@ -102,7 +102,7 @@ def test_fortran_host_testcases_3_and_5(tmp_path):
     # the "prescribe" flag set init(5) keeps commented out (mo_init.f90:1068-1071), through the namelist
     dp = tmp_path / "tc5p"
     dp.mkdir()
-    run_host(dp, "&samsim_run testcase=5, ncol=8, max_steps=40000 /\n"
+    run_host(dp, "&samsim_run testcase=5, ncol=8, max_steps=21700 /\n"
                  "&samsim_flags flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2 /\n")
     ref = golden("tc5_prescribe_ref.npz")
     T, S = load(dp, "T"), load(dp, "S_bu")

@@ -23,7 +23,7 @@ def _setup(s, cfg, st, bottom, total, q, forcing=None, clock=None):
     s.set_clock(**(clock or {}))
 
 
-@pytest.mark.parametrize("tc,nout", [(1, 40), (2, 120), (6, 90)])   # (testcase 1 runs to its end in tests/test_gpu_fortran_host.py)
+@pytest.mark.parametrize("tc,nout", [(1, 24), (2, 120), (6, 60)])   # (testcase 1 runs to its end in tests/test_gpu_fortran_host.py)
 def test_tracers_of_the_shipped_testcases(tc, nout):
     """testcases 1, 2, 6 exactly as init() ships them (tracers on): bgc_abs and bgc_bottom of the HIP path at every output
     point against the reference's records; expulsion, gravity drainage with return flow, flushing (testcase 2 melts),
