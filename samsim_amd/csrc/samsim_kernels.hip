@@ -170,13 +170,19 @@ typedef unsigned long long lu64;
 #endif
 // LDS-resident per-column scalars: slot s of lane l is word s*SAMSIM_BLOCK + l of the block's array
 enum lds_slot {
-  LD_grav_drain = 0, LD_grav_salt, LD_grav_temp, LD_melt_out1, LD_melt_out2, LD_melt_out3, LD_melt_err,
-  LD_freeboard, LD_T_freeze, LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
+  LD_grav_drain = 0, LD_grav_salt, LD_grav_temp,
+  LD_albedo, LD_fl_sw, LD_fl_lw, LD_T2m, LD_liquid_precip, LD_solid_precip,
   LD_T_top, LD_fl_Q_snow, LD_melt_thick,   // state that only the code between the sweeps touches
   LD_fl_Q1,                                // fl_Q(1) of this step (surface balance -> top-layer block, melt film): not a slot of the scalar block
+  // the snow cover: read and written before, between and after the two sweeps of every step, never inside them
+  LD_m_snow, LD_H_abs_snow, LD_thick_snow, LD_T_snow, LD_psi_s_snow, LD_melt_thick_snow,
   LD_NSLOT
 };
 #define CL(f) c.ld[LD_##f * SAMSIM_BLOCK]
+// Per-column scalars that the common step does not touch (melt-water accumulators, freeboard, T_freeze, the snow's salt and the
+// volume fractions only snow_thermo itself reads) are read and written IN PLACE in the scalar block: GS(FREEBOARD) = slot
+// SAMSIM_S_FREEBOARD of this lane's column.  19 LDS slots are what 16 one-wave workgroups per CU leave room for.
+#define GS(IDX) x.scal[(size_t)(SAMSIM_S_##IDX) * c.ncol + c.col]
 
 struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
   double c2, c3, c4, d2, d3, d4;
@@ -197,8 +203,7 @@ struct Col {
   long long err_step;
   long long step;  // completed steps; i = step + 1
   // per-column scalars (enum samsim_scalar)
-  double m_snow, H_abs_snow, S_abs_snow, thick_snow, psi_s_snow, psi_l_snow, psi_g_snow, T_snow, phi_s;
-  double fl_q_bottom, melt_thick_snow;
+  double fl_q_bottom;
   // The other per-column scalars live in LDS for the whole launch (CL(name), one 8-byte word per lane and slot, no bank
   // conflicts): accumulators (grav_*, melt_out*, melt_err), values that are set under conditions and otherwise carried
   // (freeboard, T_freeze), the forcing of the step (T2m, precipitation, albedo, short- and long-wave flux) and the ensemble
@@ -210,7 +215,7 @@ struct Col {
   double frad;       // fl_rad(N_active)
   double flq2;       // fl_Q(2), handed from the down sweep (which applies the conductive update of layers >= 2) to the top-layer block
   double esum;       // SUM(H_abs before - H_abs after the conductive update) over layers >= 2 (energy assert, mo_heat_fluxes.f90:265-310)
-  double min_psi_s;  // MINVAL(psi_s(1:N_active)) of this step's Expulsion
+  bool neg_psi;      // MINVAL(psi_s(1:N_active)) of this step's Expulsion is negative (health check at the end of the step)
   double buoy_s;     // SUM(psi_s*thick) over the active layers (from S1)
   double buoy_g;     // SUM(psi_g*thick) after expulsion_flux (from P2)
   double psi_l_top;  // psi_l(1) of this step's Expulsion (the albedo reads it before the down sweep stores the psi arrays)
@@ -246,6 +251,14 @@ struct Col {
 // SAMSIM_DAHEAD: how many layers ahead of the arithmetic the fused down sweep requests its operands (2 or 3)
 #ifndef SAMSIM_DAHEAD
 #define SAMSIM_DAHEAD 2
+#endif
+// SAMSIM_DUNROLL: the interior loop of the fused down sweep handles two layers per trip (see there)
+#ifndef SAMSIM_DUNROLL
+#define SAMSIM_DUNROLL 1
+#endif
+// SAMSIM_LAUNDER_COL: the column index is re-declared to the optimiser at every time step (see samsim_step_kernel)
+#ifndef SAMSIM_LAUNDER_COL
+#define SAMSIM_LAUNDER_COL 1
 #endif
 #ifndef SAMSIM_HORNER
 #define SAMSIM_HORNER 1
@@ -592,7 +605,7 @@ __device__ __forceinline__ bool ray_row_valid(const Col &c, const Ctx &x, int k)
 template <class K>
 __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
-  double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? c.m_snow : 0.0;
+  double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? CL(m_snow) : 0.0;
   double A = 0.0, G = 0.0;
   for (int k = 1; k <= Na; ++k) {
     double th = LAY(SAMSIM_A_THICK, k);
@@ -634,44 +647,48 @@ __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
   const Salt &s = x.salt;
   double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), S_bu = LAY(SAMSIM_A_S_BU, 1);
   double T = LAY(SAMSIM_A_T, 1), phi = LAY(SAMSIM_A_PHI, 1), H;
-  const double m_snow = c.m_snow, S_abs_snow = c.S_abs_snow;
+  const double m_snow = CL(m_snow), S_abs_snow = GS(S_ABS_SNOW);
+  double phi_sn = GS(PHI_S);
   int rc = 0;
-  H_abs = H_abs + m_snow * latent_heat + c.H_abs_snow;
-  c.H_abs_snow = -m_snow * latent_heat;
+  H_abs = H_abs + m_snow * latent_heat + CL(H_abs_snow);
+  CL(H_abs_snow) = -m_snow * latent_heat;
   H = H_abs / m;
 #define COUPLE_GETT()                                                                                      \
   do {                                                                                                     \
-    double hs = c.H_abs_snow / m_snow;                                                                     \
-    rc |= getT(s, hs, S_abs_snow / m_snow, hs / c_l, c.T_snow, c.phi_s);                                   \
+    double hs = CL(H_abs_snow) / m_snow;                                                                     \
+    double T_sn = CL(T_snow);                                                                              \
+    rc |= getT(s, hs, S_abs_snow / m_snow, hs / c_l, T_sn, phi_sn);                                        \
+    CL(T_snow) = T_sn;                                                                                     \
     rc |= getT(s, H, S_bu, H / c_l, T, phi);                                                               \
   } while (0)
   COUPLE_GETT();
-  if (T > 0.0 && H_abs <= -c.H_abs_snow) {
-    c.H_abs_snow = c.H_abs_snow + H_abs;
+  if (T > 0.0 && H_abs <= -CL(H_abs_snow)) {
+    CL(H_abs_snow) = CL(H_abs_snow) + H_abs;
     H_abs = 0.0;
     COUPLE_GETT();
-  } else if (T > 0.0 && H_abs > -c.H_abs_snow) {
-    H_abs = (H_abs + c.H_abs_snow) * m / m_snow / (1.0 + m / m_snow);
-    c.H_abs_snow = H_abs * m_snow / m;
+  } else if (T > 0.0 && H_abs > -CL(H_abs_snow)) {
+    H_abs = (H_abs + CL(H_abs_snow)) * m / m_snow / (1.0 + m / m_snow);
+    CL(H_abs_snow) = H_abs * m_snow / m;
     COUPLE_GETT();
   } else {
     int jj = 0;
-    while (fabs(T - c.T_snow) > (double)0.1f && jj < 201) {
-      double d = c.T_snow - (c.T_snow + T) / 2.0;
+    while (fabs(T - CL(T_snow)) > (double)0.1f && jj < 201) {
+      double d = CL(T_snow) - (CL(T_snow) + T) / 2.0;
       double sg = dmax(fabs(d), 0.1);
       if (signbit(d)) sg = -sg;
-      c.H_abs_snow = c.H_abs_snow - sg * c_s * m_snow;
+      CL(H_abs_snow) = CL(H_abs_snow) - sg * c_s * m_snow;
       H_abs = H_abs + sg * c_s * m_snow;
       jj = jj + 1;
       H = H_abs / m;
       COUPLE_GETT();
     }
-    if (jj > 200 && fabs(T - c.T_snow) > 1.0) rc = 16;
+    if (jj > 200 && fabs(T - CL(T_snow)) > 1.0) rc = 16;
   }
 #undef COUPLE_GETT
   LAY(SAMSIM_A_H_ABS, 1) = H_abs;
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
+  GS(PHI_S) = phi_sn;
   if (rc) STOPC(rc == 16 ? 16 : 99, 1);
 }
 
@@ -688,11 +705,11 @@ __device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
   else { solid = CL(liquid_precip); liquid = 0.0; }
   if (c.Na > 1) {
     double d_thick = dt * solid * rho_l / rho_snow;
-    c.m_snow = c.m_snow + dt * rho_l * (liquid + solid);
-    c.thick_snow = c.thick_snow + d_thick;
-    c.H_abs_snow = c.H_abs_snow + dt * T2m * liquid * rho_l * c_l;
-    c.H_abs_snow = c.H_abs_snow + dt * dmin(T2m, -1.0) * solid * rho_l * c_s;
-    c.H_abs_snow = c.H_abs_snow - dt * solid * rho_l * latent_heat;
+    CL(m_snow) = CL(m_snow) + dt * rho_l * (liquid + solid);
+    CL(thick_snow) = CL(thick_snow) + d_thick;
+    CL(H_abs_snow) = CL(H_abs_snow) + dt * T2m * liquid * rho_l * c_l;
+    CL(H_abs_snow) = CL(H_abs_snow) + dt * dmin(T2m, -1.0) * solid * rho_l * c_s;
+    CL(H_abs_snow) = CL(H_abs_snow) - dt * solid * rho_l * latent_heat;
   } else {
     double H_abs = LAY(SAMSIM_A_H_ABS, 1), S_abs = LAY(SAMSIM_A_S_ABS, 1);
     const double m = LAY(SAMSIM_A_M, 1), T = LAY(SAMSIM_A_T, 1);
@@ -709,94 +726,105 @@ __device__ __forceinline__ void snow_fall(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void snow_block(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
-  if (!(c.thick_snow > 0.0)) {
-    c.thick_snow = 0.0; c.m_snow = 0.0; c.psi_s_snow = 0.0; c.psi_l_snow = 0.0; c.psi_g_snow = 0.0;
-    c.H_abs_snow = 0.0; c.S_abs_snow = 0.0; c.melt_thick_snow = 0.0;
+  // (psi_l_snow, psi_g_snow and S_abs_snow are only read by this routine and by rare events -- flooding, the melting of a thin
+  // cover, melt water from the snow: they live in the scalar block, which is written where a value changes)
+  if (!(CL(thick_snow) > 0.0)) {
+    if ((c.flags & COLF_RESTART) || CL(m_snow) != 0.0 || CL(thick_snow) != 0.0 || CL(psi_s_snow) != 0.0 || CL(H_abs_snow) != 0.0) {   // the cover has just gone (or the state is new)
+      GS(PSI_L_SNOW) = 0.0; GS(PSI_G_SNOW) = 0.0; GS(S_ABS_SNOW) = 0.0;
+    }
+    CL(thick_snow) = 0.0; CL(m_snow) = 0.0; CL(psi_s_snow) = 0.0;
+    CL(H_abs_snow) = 0.0; CL(melt_thick_snow) = 0.0;
     return;
   }
-  c.melt_thick_snow = 0.0;
+  double psi_l_sn, psi_g_sn;
+  const double S_abs_sn = GS(S_ABS_SNOW);
+  CL(melt_thick_snow) = 0.0;
   const bool meltwater = (CFG(snow_flush_flag) == 1);
   double m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1), H_abs = LAY(SAMSIM_A_H_ABS, 1);
   bool touched = false;
   double phi_snow = 0.0, max_lwc, max_lwc_v, sat_snow;
-  const double H_snow = c.H_abs_snow / c.m_snow, S_bu_snow = c.S_abs_snow / c.m_snow, psi_s_old = c.psi_s_snow;
-  const double T_in = c.T_snow;
-  int rc = getT(x.salt, H_snow, S_bu_snow, T_in, c.T_snow, phi_snow);
+  const double H_snow = CL(H_abs_snow) / CL(m_snow), S_bu_snow = S_abs_sn / CL(m_snow), psi_s_old = CL(psi_s_snow);
+  const double T_in = CL(T_snow);
+  double T_sn = T_in;
+  int rc = getT(x.salt, H_snow, S_bu_snow, T_in, T_sn, phi_snow);
+  CL(T_snow) = T_sn;
   if (rc) STOPC(99, 0);
-  c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
-  c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
-  if (c.psi_s_snow + c.psi_l_snow > 1.0) {
-    c.thick_snow = c.m_snow * (phi_snow / rho_s + (1.0 - phi_snow) / rho_l);
-    c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
-    c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
-    if (fabs(c.psi_s_snow + c.psi_l_snow - 1.0) > 0.0000001) STOPC(345, 0);
+  CL(psi_s_snow) = CL(m_snow) * phi_snow / rho_s / CL(thick_snow);
+  psi_l_sn = CL(m_snow) * (1.0 - phi_snow) / rho_l / CL(thick_snow);
+  if (CL(psi_s_snow) + psi_l_sn > 1.0) {
+    CL(thick_snow) = CL(m_snow) * (phi_snow / rho_s + (1.0 - phi_snow) / rho_l);
+    CL(psi_s_snow) = CL(m_snow) * phi_snow / rho_s / CL(thick_snow);
+    psi_l_sn = CL(m_snow) * (1.0 - phi_snow) / rho_l / CL(thick_snow);
+    if (fabs(CL(psi_s_snow) + psi_l_sn - 1.0) > 0.0000001) { GS(PSI_L_SNOW) = psi_l_sn; STOPC(345, 0); }
   }
-  c.psi_g_snow = 1.0 - c.psi_s_snow - c.psi_l_snow;
-  if (c.psi_s_snow > 0.0) max_lwc = 0.057 * (1.0 - c.psi_s_snow) / (c.psi_s_snow) + 0.017;
+  psi_g_sn = 1.0 - CL(psi_s_snow) - psi_l_sn;
+  if (CL(psi_s_snow) > 0.0) max_lwc = 0.057 * (1.0 - CL(psi_s_snow)) / (CL(psi_s_snow)) + 0.017;
   else max_lwc = 0.0;
 
-  if (psi_s_old > c.psi_s_snow && c.psi_s_snow > 0.0) {
-    if ((1.0 - phi_snow) > max_lwc) c.thick_snow = c.thick_snow * (1.0 - (psi_s_old - c.psi_s_snow) / psi_s_old);
-    double tmin = (phi_snow * c.m_snow / rho_s + (1.0 - phi_snow) * c.m_snow / rho_l);
-    if (c.thick_snow < tmin) c.thick_snow = tmin;
-    c.psi_s_snow = c.m_snow * phi_snow / rho_s / c.thick_snow;
-    c.psi_l_snow = c.m_snow * (1.0 - phi_snow) / rho_l / c.thick_snow;
-    c.psi_g_snow = 1.0 - c.psi_s_snow - c.psi_l_snow;
-    c.psi_g_snow = fabs(c.psi_g_snow);
-  } else if (c.psi_s_snow < 0.000001) {
-    c.thick_snow = c.m_snow / rho_l;
-    c.psi_s_snow = 0.0; c.psi_g_snow = 0.0; c.psi_l_snow = 1.0;
+  if (psi_s_old > CL(psi_s_snow) && CL(psi_s_snow) > 0.0) {
+    if ((1.0 - phi_snow) > max_lwc) CL(thick_snow) = CL(thick_snow) * (1.0 - (psi_s_old - CL(psi_s_snow)) / psi_s_old);
+    double tmin = (phi_snow * CL(m_snow) / rho_s + (1.0 - phi_snow) * CL(m_snow) / rho_l);
+    if (CL(thick_snow) < tmin) CL(thick_snow) = tmin;
+    CL(psi_s_snow) = CL(m_snow) * phi_snow / rho_s / CL(thick_snow);
+    psi_l_sn = CL(m_snow) * (1.0 - phi_snow) / rho_l / CL(thick_snow);
+    psi_g_sn = 1.0 - CL(psi_s_snow) - psi_l_sn;
+    psi_g_sn = fabs(psi_g_sn);
+  } else if (CL(psi_s_snow) < 0.000001) {
+    CL(thick_snow) = CL(m_snow) / rho_l;
+    CL(psi_s_snow) = 0.0; psi_g_sn = 0.0; psi_l_sn = 1.0;
   }
 
-  const bool wet = (1.0 - phi_snow) > max_lwc && c.psi_g_snow > 0.0 && (!meltwater || c.psi_l_snow > 0.0);
+  const bool wet = (1.0 - phi_snow) > max_lwc && psi_g_sn > 0.0 && (!meltwater || psi_l_sn > 0.0);
   if (wet) {
     touched = true;
-    const double T_snow = c.T_snow, pss = c.psi_s_snow;
-    max_lwc_v = max_lwc * c.m_snow / (rho_l * c.thick_snow);
+    const double T_snow = CL(T_snow), pss = CL(psi_s_snow);
+    max_lwc_v = max_lwc * CL(m_snow) / (rho_l * CL(thick_snow));
     if (!meltwater) {
-      sat_snow = c.thick_snow * (c.psi_l_snow - max_lwc_v);
-      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, c.psi_g_snow));
-      c.thick_snow = c.thick_snow - sat_snow;
+      sat_snow = CL(thick_snow) * (psi_l_sn - max_lwc_v);
+      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, psi_g_sn));
+      CL(thick_snow) = CL(thick_snow) - sat_snow;
       thick = thick + sat_snow;
-      c.m_snow = c.m_snow - sat_snow * (pss * rho_s + (1.0 - pss - gas_snow_ice2) * rho_l);
+      CL(m_snow) = CL(m_snow) - sat_snow * (pss * rho_s + (1.0 - pss - gas_snow_ice2) * rho_l);
       m = m + sat_snow * (pss * rho_s + (1.0 - pss - gas_snow_ice2) * rho_l);
-      c.H_abs_snow = c.H_abs_snow - sat_snow * pss * rho_s * c_s * T_snow;
+      CL(H_abs_snow) = CL(H_abs_snow) - sat_snow * pss * rho_s * c_s * T_snow;
       H_abs = H_abs + sat_snow * pss * rho_s * c_s * T_snow;
-      c.H_abs_snow = c.H_abs_snow + sat_snow * pss * rho_s * latent_heat;
+      CL(H_abs_snow) = CL(H_abs_snow) + sat_snow * pss * rho_s * latent_heat;
       H_abs = H_abs - sat_snow * pss * rho_s * latent_heat;
-      c.H_abs_snow = c.H_abs_snow - sat_snow * (1.0 - pss) * rho_l * c_l * T_snow;
+      CL(H_abs_snow) = CL(H_abs_snow) - sat_snow * (1.0 - pss) * rho_l * c_l * T_snow;
       H_abs = H_abs + sat_snow * (1.0 - pss) * rho_l * c_l * T_snow;
     } else {
       const double ksf = g.k_snow_flush;
-      double slush = (c.psi_l_snow - max_lwc_v) * (1.0 - ksf);
-      double flush = (c.psi_l_snow - max_lwc_v) * ksf;
-      c.melt_thick_snow = c.thick_snow * flush;
-      sat_snow = c.thick_snow * (slush);
-      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, c.psi_g_snow));
-      const double gmin = dmin(gas_snow_ice2, c.psi_g_snow);
-      c.thick_snow = c.thick_snow - sat_snow - c.melt_thick_snow;
+      double slush = (psi_l_sn - max_lwc_v) * (1.0 - ksf);
+      double flush = (psi_l_sn - max_lwc_v) * ksf;
+      CL(melt_thick_snow) = CL(thick_snow) * flush;
+      sat_snow = CL(thick_snow) * (slush);
+      sat_snow = sat_snow / (1.0 - pss - max_lwc_v - dmin(gas_snow_ice2, psi_g_sn));
+      const double gmin = dmin(gas_snow_ice2, psi_g_sn);
+      CL(thick_snow) = CL(thick_snow) - sat_snow - CL(melt_thick_snow);
       thick = thick + sat_snow;
-      c.m_snow = c.m_snow - sat_snow * (pss * rho_s + (1.0 - pss - gmin) * rho_l) - c.melt_thick_snow * rho_l;
+      CL(m_snow) = CL(m_snow) - sat_snow * (pss * rho_s + (1.0 - pss - gmin) * rho_l) - CL(melt_thick_snow) * rho_l;
       m = m + sat_snow * (pss * rho_s + (1.0 - pss - gmin) * rho_l);
-      c.H_abs_snow = c.H_abs_snow - sat_snow * pss * rho_s * c_s * T_snow;
+      CL(H_abs_snow) = CL(H_abs_snow) - sat_snow * pss * rho_s * c_s * T_snow;
       H_abs = H_abs + sat_snow * pss * rho_s * c_s * T_snow;
-      c.H_abs_snow = c.H_abs_snow + sat_snow * pss * rho_s * latent_heat;
+      CL(H_abs_snow) = CL(H_abs_snow) + sat_snow * pss * rho_s * latent_heat;
       H_abs = H_abs - sat_snow * pss * rho_s * latent_heat;
-      c.H_abs_snow = c.H_abs_snow - sat_snow * (1.0 - pss - gmin) * rho_l * c_l * T_snow - c.melt_thick_snow * rho_l * c_l * T_snow;
+      CL(H_abs_snow) = CL(H_abs_snow) - sat_snow * (1.0 - pss - gmin) * rho_l * c_l * T_snow - CL(melt_thick_snow) * rho_l * c_l * T_snow;
       H_abs = H_abs + sat_snow * (1.0 - pss - gmin) * rho_l * c_l * T_snow;
     }
-  } else if (c.psi_g_snow <= 0.0) {
+  } else if (psi_g_sn <= 0.0) {
     touched = true;
-    H_abs = H_abs + c.H_abs_snow; m = m + c.m_snow; thick = thick + c.thick_snow;
-    c.H_abs_snow = 0.0; c.m_snow = 0.0; c.thick_snow = 0.0;
-    c.psi_g_snow = 0.0; c.psi_s_snow = 0.0; c.psi_l_snow = 0.0;
+    H_abs = H_abs + CL(H_abs_snow); m = m + CL(m_snow); thick = thick + CL(thick_snow);
+    CL(H_abs_snow) = 0.0; CL(m_snow) = 0.0; CL(thick_snow) = 0.0;
+    psi_g_sn = 0.0; CL(psi_s_snow) = 0.0; psi_l_sn = 0.0;
   }
   if (touched) {
     LAY(SAMSIM_A_M, 1) = m;
     LAY(SAMSIM_A_THICK, 1) = thick;
     LAY(SAMSIM_A_H_ABS, 1) = H_abs;
   }
-  if (c.psi_g_snow < 0.0) STOPC(9876, 0);
+  GS(PSI_L_SNOW) = psi_l_sn;
+  GS(PSI_G_SNOW) = psi_g_sn;
+  if (psi_g_sn < 0.0) STOPC(9876, 0);
 }
 
 // ---------------------------------------------------------------- S1: first thermodynamic sweep, bottom -> top
@@ -926,7 +954,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_PHI, k) = phi;
     s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
   }
-  c.min_psi_s = r.min_psi_s;
+  c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   c.flags = regular ? (c.flags | COLF_REGULAR) : (c.flags & ~COLF_REGULAR);
   if (rc) STOPC(rc, rc_layer);
@@ -955,7 +983,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
   s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, r);
-  c.min_psi_s = r.min_psi_s;
+  c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, 1);
 }
@@ -1050,12 +1078,12 @@ __device__ RARE void vital_signs(Col &c, const Ctx &x) {
     }
   }
   const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
-  c.energy_stored = c.H_abs_snow + sH - g.T_bottom * sm * c_l;
+  c.energy_stored = CL(H_abs_snow) + sH - g.T_bottom * sm * c_l;
   c.freshwater = sm / rho_l;
   c.freshwater = c.freshwater * (1.0 - sS / sm / ref_salinity);
-  c.freshwater = c.freshwater + c.m_snow / rho_l;
+  c.freshwater = c.freshwater + CL(m_snow) / rho_l;
   resist = resist + thN * psN / psi_s_min * (psi_s_min * k_s + 1.0 - psi_s_min * k_l);
-  if (c.thick_snow > g.thick_min / 110.0) resist = resist + c.thick_snow / func_k_snow(c.m_snow, c.thick_snow);
+  if (CL(thick_snow) > g.thick_min / 110.0) resist = resist + CL(thick_snow) / func_k_snow(CL(m_snow), CL(thick_snow));
   c.total_resist = resist;
   c.thickness = ((Na > 1) ? sth : 0.0) + thN * psN / psi_s_min;
   if (Na > 1) {
@@ -1083,7 +1111,7 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   hp = hp + (thN * psN / psi_s_min) / permN;
   hp = (sth + thN * psN / psi_s_min) / hp;
   const double sall = sth + thN;
-  const double freeboard = CL(freeboard), psi_g_snow = c.psi_g_snow;
+  const double freeboard = GS(FREEBOARD), psi_g_snow = GS(PSI_G_SNOW);
   double flood_brine = -g.dt * grav_f * rho_l * rho_l * hp * (freeboard) / (mu * sall);
   const double shift_ice = flood_brine / (rho_l * psi_g_snow / ratio_flood);
   const double shift_snow = shift_ice * (1 + psi_g_snow / (1.0 - psi_g_snow) * (1.0 - 1.0 / ratio_flood));
@@ -1097,11 +1125,11 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   H1 = H1 + flood_brine * HN / mN;
   m1 = m1 + flood_brine;
   th1 = th1 + shift_ice;
-  H1 = H1 + shift_snow / c.thick_snow * c.H_abs_snow;
-  c.H_abs_snow = c.H_abs_snow - shift_snow / c.thick_snow * c.H_abs_snow;
-  m1 = m1 + shift_snow / c.thick_snow * c.m_snow;
-  c.m_snow = c.m_snow - shift_snow / c.thick_snow * c.m_snow;
-  c.thick_snow = c.thick_snow - shift_snow;
+  H1 = H1 + shift_snow / CL(thick_snow) * CL(H_abs_snow);
+  CL(H_abs_snow) = CL(H_abs_snow) - shift_snow / CL(thick_snow) * CL(H_abs_snow);
+  m1 = m1 + shift_snow / CL(thick_snow) * CL(m_snow);
+  CL(m_snow) = CL(m_snow) - shift_snow / CL(thick_snow) * CL(m_snow);
+  CL(thick_snow) = CL(thick_snow) - shift_snow;
 
   if (freeboard + shift_ice < neg_free) {
     const double shift = neg_free - (freeboard + shift_ice);
@@ -1112,11 +1140,11 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
     H1 = H1 + TN * c_l * flood_brine;
     m1 = m1 + flood_brine;
     th1 = th1 + shift;
-    H1 = H1 + shift / c.thick_snow * c.H_abs_snow;
-    c.H_abs_snow = c.H_abs_snow - shift / c.thick_snow * c.H_abs_snow;
-    m1 = m1 + shift / c.thick_snow * c.m_snow;
-    c.m_snow = c.m_snow - shift / c.thick_snow * c.m_snow;
-    c.thick_snow = c.thick_snow - shift;
+    H1 = H1 + shift / CL(thick_snow) * CL(H_abs_snow);
+    CL(H_abs_snow) = CL(H_abs_snow) - shift / CL(thick_snow) * CL(H_abs_snow);
+    m1 = m1 + shift / CL(thick_snow) * CL(m_snow);
+    CL(m_snow) = CL(m_snow) - shift / CL(thick_snow) * CL(m_snow);
+    CL(thick_snow) = CL(thick_snow) - shift;
     LAY(SAMSIM_A_S_ABS, Na) = SN;
     LAY(SAMSIM_A_H_ABS, Na) = HN;
   }
@@ -1131,18 +1159,18 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void flood_simple(Col &c, const Ctx &x) {
   const samsim_config &g = x.p->cfg;
-  const double shift = CL(freeboard) - neg_free;
-  const double flood_brine = -shift * c.psi_g_snow * rho_l;
+  const double shift = GS(FREEBOARD) - neg_free;
+  const double flood_brine = -shift * GS(PSI_G_SNOW) * rho_l;
   double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
   th1 = th1 - shift;
   S1 = S1 + x.S_bu_bottom * flood_brine;
-  H1 = H1 - shift / c.thick_snow * c.H_abs_snow;
+  H1 = H1 - shift / CL(thick_snow) * CL(H_abs_snow);
   H1 = H1 + g.T_bottom * c_l * flood_brine;
-  m1 = m1 - shift / c.thick_snow * c.m_snow;
+  m1 = m1 - shift / CL(thick_snow) * CL(m_snow);
   m1 = m1 + flood_brine;
-  c.H_abs_snow = c.H_abs_snow + shift / c.thick_snow * c.H_abs_snow;
-  c.m_snow = c.m_snow + shift / c.thick_snow * c.m_snow;
-  c.thick_snow = c.thick_snow + shift;
+  CL(H_abs_snow) = CL(H_abs_snow) + shift / CL(thick_snow) * CL(H_abs_snow);
+  CL(m_snow) = CL(m_snow) + shift / CL(thick_snow) * CL(m_snow);
+  CL(thick_snow) = CL(thick_snow) + shift;
   LAY(SAMSIM_A_S_ABS, 1) = S1;
   LAY(SAMSIM_A_H_ABS, 1) = H1;
   LAY(SAMSIM_A_M, 1) = m1;
@@ -1439,7 +1467,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
   // runs after the loop (once per wave, every lane with its own j), so that the loop body -- the interior layers -- carries
   // neither the bottom-layer work (gas -> ocean water, the bottom turbulence with its exp and two pow) nor its registers.
-  auto layer = [&](const int j, auto last_tag) {
+  auto layer = [&](const int j, const Ld &below, auto last_tag) {   // below: the request buffer that holds layer j+1
     constexpr bool LAST = decltype(last_tag)::value;
     // ---- A(j)
     const double thick = raw.thick;
@@ -1500,7 +1528,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     if (!LAST) {
       const double ray = raw.ray;
       // S_br(j+1) of the first sweep, from the request buffer of layer j+1 (same operands and operations as finish())
-      if (ray > ray_crit && S_br > S_br_below(ahead)) {
+      if (ray > ray_crit && S_br > S_br_below(below)) {
         const double psi_s = ex.psi_s;
         if (psi_s > 0.001 && quot(SA, mA) > 0.1) {  // S_bu of this layer (j < N_active: nothing changed since A)
           ST_COUNT(CT_DRAIN_WAVE, 1);
@@ -1554,8 +1582,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   auto request = [&](const int j) { ahead2 = load_ld(j + 2 <= N ? j + 2 : N); };      // top of iteration j: layer j+2
   auto advance = [&](const int j) { raw = finish(ahead, j + 1); ahead = ahead2; };      // end of iteration j: layer j+1 becomes current
   // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
-  if (1 < Na) { request(1); layer(1, std::false_type{}); advance(1); }
-  if (2 < Na) { request(2); layer(2, std::false_type{}); advance(2); }
+  if (1 < Na) { request(1); layer(1, ahead, std::false_type{}); advance(1); }
+  if (2 < Na) { request(2); layer(2, ahead, std::false_type{}); advance(2); }
   // ---- Who reads the psi_s / psi_l / psi_g rows of the layers below?  The vital signs at the next output point and a get_state
   // after the launch (force_psi), and -- when the surface melts or the snow releases melt water -- func_freeboard and flush3
   // (mo_grotz.f90:636,670,717-725).  With N_active >= 3 layer 1 is complete by now (its return-flow transfer C(1) ran with
@@ -1571,28 +1599,64 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     const double thick_min = g.thick_min;
     const double Tf = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
     bool snow_wet = false;
-    if (c.thick_snow > 0.0) {
+    if (CL(thick_snow) > 0.0) {
       // snow_thermo finds liquid water iff H_abs_snow / m_snow > -latent_heat (getT's fresh branch); the up sweep adds
       // (fl_Q(1) - fl_Q_snow)*dt to a snow cover thicker than thick_min (thinner ones take the unfused path: never here)
-      const double H_new = c.H_abs_snow + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
-      snow_wet = !(c.thick_snow >= thick_min) || !(H_new / c.m_snow <= -latent_heat);
+      const double H_new = CL(H_abs_snow) + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
+      snow_wet = !(CL(thick_snow) >= thick_min) || !(H_new / CL(m_snow) <= -latent_heat);
     }
-    store_psi = store_default || LAY(SAMSIM_A_PSI_S, 1) < psi_s_top_min || CL(T_top) >= Tf || snow_wet || c.melt_thick_snow > 0.0;
+    store_psi = store_default || LAY(SAMSIM_A_PSI_S, 1) < psi_s_top_min || CL(T_top) >= Tf || snow_wet || CL(melt_thick_snow) > 0.0;
   } else {
     store_psi = store_default || decide_psi;   // (a deciding sweep over fewer than three layers has nothing left to skip)
   }
   c.psi_full = store_psi;
+#if SAMSIM_DUNROLL
+  // The interior layers 3 <= j < N_active, two per trip: the two request buffers swap roles from one layer to the next, so with
+  // both layers in one loop body no buffer is copied into the other (and the hand-over of layer j to C(j) of the next layer is a
+  // renaming): the single-layer loop spent 35 of its 265 vector instructions on those copies.
+  {
+    int j = 3;
+    for (; j + 1 < jmax; j += 2) {
+      ISA_MARK("D_ITER_BEGIN");
+      ST_MARK(ST_DFUSED);
+      if (j + 1 < Na) {                                  // both layers are interior layers of this column: one straight-line body
+        ST_COUNT(CT_DOWN_TRIPS, 2);
+        ahead2 = load_ld(j + 2 <= N ? j + 2 : N);        // layer j+2 -> second buffer
+        layer(j, ahead, std::false_type{});
+        raw = finish(ahead, j + 1);
+        ahead = load_ld(j + 3 <= N ? j + 3 : N);         // layer j+3 -> first buffer
+        layer(j + 1, ahead2, std::false_type{});
+        raw = finish(ahead2, j + 2);
+      }
+#ifndef SAMSIM_DUNROLL_NOELSE
+      else if (j < Na) {                               // layer j is the column's last interior layer
+        ST_COUNT(CT_DOWN_TRIPS, 1);
+        ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
+        layer(j, ahead, std::false_type{});
+        raw = finish(ahead, j + 1);
+      }
+#endif
+      ISA_MARK("D_ITER_END");
+    }
+    if (j < jmax && j < Na) {                            // odd number of interior layers in the longest column of the wave
+      ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
+      layer(j, ahead, std::false_type{});
+      raw = finish(ahead, j + 1);
+    }
+  }
+#else
   for (int j = 3; j < jmax; ++j) {                     // the interior layers 3 <= j < N_active
     ISA_MARK("D_ITER_BEGIN");
     ST_MARK(ST_DFUSED);
     if (j >= Na) continue;
     ST_COUNT(CT_DOWN_TRIPS, 1);
     request(j);
-    layer(j, std::false_type{});
+    layer(j, ahead, std::false_type{});
     advance(j);
     ISA_MARK("D_ITER_END");
   }
-  layer(Na, std::true_type{});                         // the bottom layer (this sweep only runs with N_active >= 2)
+#endif
+  layer(Na, ahead, std::true_type{});                  // the bottom layer (this sweep only runs with N_active >= 2)
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
     prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
@@ -1630,7 +1694,7 @@ template <class K>
 __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double time, int tc) {
   const samsim_config &g = x.p->cfg;
   if (CFG(boundflux_flag) != 2) return 0.0;
-  CL(albedo) = func_albedo(c.thick_snow, c.T_snow, c.psi_l_top, g.thick_min, CFG(albedo_flag));
+  CL(albedo) = func_albedo(CL(thick_snow), CL(T_snow), c.psi_l_top, g.thick_min, CFG(albedo_flag));
   if (!K::general || CFG(atmoflux_flag) == 2) {
     if (time == time_input(tc)) {
       CL(fl_sw) = x.f_sw[x.soff + tc - 1];
@@ -1650,16 +1714,16 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
     if (day < 60.0 || day > 300.0) CL(fl_sw) = 0.0;
     x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col] = 118.0 * exp(-0.5 * (b * b)) + 179.0;
   }
-  const double pen = (c.thick_snow < g.thick_min) ? penetr : 0.0;
+  const double pen = (CL(thick_snow) < g.thick_min) ? penetr : 0.0;
   return pen * (1.0 - CL(albedo)) * CL(fl_sw);
 }
 
 // twice-iterated linearised radiative balance for the surface temperature, mo_heat_fluxes.f90:115-148: a function of the
 // forcing, the albedo, and the temperature of the snow (or of the top layer under thin / no snow)
 __device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, double T1, double thick_min) {
-  double T_old = (c.thick_snow < thick_min) ? T1 : c.T_snow;
-  const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
-  const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
+  double T_old = (CL(thick_snow) < thick_min) ? T1 : CL(T_snow);
+  const double emi = (CL(thick_snow) < thick_min) ? emissivity_ice : emissivity_snow;
+  const double pen = (CL(thick_snow) < thick_min) ? penetr : 0.0;
   T_old = T_old + zeroK;
   double temp1 = (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) + fl_rest;
   temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
@@ -1687,11 +1751,11 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
     return;
   }
   if (K::general && CFG(boundflux_flag) == 3) {  // lab air temperature, mo_heat_fluxes.f90:202-219 (lab_snow_flag 0)
-    CL(T_freeze) = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
+    GS(T_FREEZE) = dmin(func_T_freeze(LAY(SAMSIM_A_S_ABS, Na) / LAY(SAMSIM_A_M, Na), CFG(salt_flag), x.tf_c3), 0.0);
     CL(T_top) = T1;
     CL(fl_Q1) = g.alpha_flux_instable * (CL(T_top) - CL(T2m));
     if (CL(fl_Q1) < 0.0) {
-      CL(T_top) = dmax(CL(T_freeze), T1);
+      CL(T_top) = dmax(GS(T_FREEZE), T1);
       CL(fl_Q1) = g.alpha_flux_stable * (CL(T_top) - CL(T2m));
     }
     return;
@@ -1699,32 +1763,35 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
   const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? CL(fl_lw) + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
-  const double emi = (c.thick_snow < thick_min) ? emissivity_ice : emissivity_snow;
-  const double pen = (c.thick_snow < thick_min) ? penetr : 0.0;
+  const double emi = (CL(thick_snow) < thick_min) ? emissivity_ice : emissivity_snow;
+  const double pen = (CL(thick_snow) < thick_min) ? penetr : 0.0;
   double temp1;
   CL(T_top) = radiative_T_top(c, fl_rest, T1, thick_min);
 
-  if (c.thick_snow >= thick_min / 100.0) CL(T_freeze) = 0.0;
-  else CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+  double Tf;
+  if (CL(thick_snow) >= thick_min / 100.0) Tf = 0.0;
+  else Tf = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
 
-  const double k_snow = (c.thick_snow >= thick_min / 100.0) ? func_k_snow(c.m_snow, c.thick_snow) : 0.0;
+  GS(T_FREEZE) = Tf;
+
+  const double k_snow = (CL(thick_snow) >= thick_min / 100.0) ? func_k_snow(CL(m_snow), CL(thick_snow)) : 0.0;
   // sub_fl_Q_snow, mo_snow.f90:498-518
-  const double flq_snow_ice = (T1 - c.T_snow) / (c.thick_snow / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
-  if (CL(T_top) > CL(T_freeze) && Na > 1) {
-    temp1 = emi * sigma * pow(CL(T_freeze) + zeroK, 4.0) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
-    if (c.thick_snow >= thick_min) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = flq_snow_ice; }
-    else if (c.thick_snow >= thick_min / 100.0) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = 0.0; }
+  const double flq_snow_ice = (T1 - CL(T_snow)) / (CL(thick_snow) / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
+  if (CL(T_top) > Tf && Na > 1) {
+    temp1 = emi * sigma * pow(Tf + zeroK, 4.0) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
+    if (CL(thick_snow) >= thick_min) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = flq_snow_ice; }
+    else if (CL(thick_snow) >= thick_min / 100.0) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = 0.0; }
     else CL(fl_Q1) = temp1;
-    CL(T_top) = CL(T_freeze);
+    CL(T_top) = Tf;
   } else {
-    if (c.thick_snow >= thick_min) {
+    if (CL(thick_snow) >= thick_min) {
       CL(fl_Q1) = flq_snow_ice;
-      CL(fl_Q_snow) = (c.T_snow - CL(T_top)) / (c.thick_snow / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
-    } else if (c.thick_snow > thick_min / 100.0 && c.thick_snow < thick_min) {
+      CL(fl_Q_snow) = (CL(T_snow) - CL(T_top)) / (CL(thick_snow) / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
+    } else if (CL(thick_snow) > thick_min / 100.0 && CL(thick_snow) < thick_min) {
       CL(fl_Q1) = 0.0;
       // sub_fl_Q_0_snow_thin, mo_snow.f90:466-487
-      double k = c.thick_snow / (c.thick_snow + thick1) * k_snow + thick1 / (c.thick_snow + thick1) * k1;
-      CL(fl_Q_snow) = (c.T_snow - CL(T_top)) / ((c.thick_snow + thick1) / (2.0 * k));
+      double k = CL(thick_snow) / (CL(thick_snow) + thick1) * k_snow + thick1 / (CL(thick_snow) + thick1) * k1;
+      CL(fl_Q_snow) = (CL(T_snow) - CL(T_top)) / ((CL(thick_snow) + thick1) / (2.0 * k));
     } else {
       CL(fl_Q1) = (T1 - CL(T_top)) / (thick1 / (2.0 * k1));
     }
@@ -1745,10 +1812,10 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   const Salt &s = x.salt;
   const int Na = c.Na;
   const double dt = g.dt, thick_min = g.thick_min;
-  const bool thin_snow = (c.thick_snow >= thick_min / 100.0 && c.thick_snow < thick_min);
+  const bool thin_snow = (CL(thick_snow) >= thick_min / 100.0 && CL(thick_snow) < thick_min);
   const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   const bool keep_ray = next_is_output && col >= x.out_col0 && col < x.out_col0 + x.out_ncols;
-  const double H_abs_snow_before = c.H_abs_snow;
+  const double H_abs_snow_before = CL(H_abs_snow);
   double esum = c.esum;   // SUM(H_abs before - after the conductive update) over the layers >= 2, from the down sweep
   double T_test = g.T_bottom;
   int rc = 0, rc_layer = 0;
@@ -1799,13 +1866,13 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       H_abs = H_abs + c.frad * dt;
       // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
-        c.H_abs_snow = c.H_abs_snow - CL(fl_Q_snow) * dt;
+        CL(H_abs_snow) = CL(H_abs_snow) - CL(fl_Q_snow) * dt;
         LAY(SAMSIM_A_H_ABS, 1) = H_abs;
         snow_coupling<K>(c, x);
         if (c.status) { alive = false; return; }
         H_abs = LAY(SAMSIM_A_H_ABS, 1);
-      } else if (c.thick_snow >= thick_min) {
-        c.H_abs_snow = c.H_abs_snow + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
+      } else if (CL(thick_snow) >= thick_min) {
+        CL(H_abs_snow) = CL(H_abs_snow) + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
       }
       esum += H_b - H_abs;   // (after the thin-snow coupling, which moves enthalpy between the snow and layer 1)
       LAY(SAMSIM_A_H_ABS, 1) = H_abs;
@@ -1862,9 +1929,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   SPEC(SP_SBR_BOT) = r.S_br_bot; SPEC(SP_BUOY_S) = r.buoy_s; SPEC(SP_MIN_PSI_S) = r.min_psi_s;
   // energy conservation assert, mo_heat_fluxes.f90:265-310: (SUM(H_abs) + H_abs_snow) before + what went in - the same after,
   // with the two sums taken as one sum of per-layer differences
-  double bal = esum + (H_abs_snow_before - c.H_abs_snow);
+  double bal = esum + (H_abs_snow_before - CL(H_abs_snow));
   bal = bal + (double)Na * (c.frad * dt);
-  if (thin_snow || c.thick_snow >= thick_min) bal = bal + c.fl_q_bottom * dt - CL(fl_Q_snow) * dt;
+  if (thin_snow || CL(thick_snow) >= thick_min) bal = bal + c.fl_q_bottom * dt - CL(fl_Q_snow) * dt;
   else bal = bal + c.fl_q_bottom * dt - CL(fl_Q1) * dt;
   if (rc) STOPC(rc, rc_layer);
   if (fabs(bal / dt) > 0.00001) STOPC(431, 0);
@@ -1930,9 +1997,9 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     R_below = R;
   }
   const double R1 = R_below;
-  double flush_total = (CL(freeboard) + CL(melt_thick)) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
+  double flush_total = (GS(FREEBOARD) + CL(melt_thick)) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
   flush_total = dmin(flush_total, CL(melt_thick) * rho_l);
-  CL(melt_err) = CL(melt_err) + CL(melt_thick) - dmin(flush_total / rho_l, CL(melt_thick));
+  GS(MELT_ERR) = GS(MELT_ERR) + CL(melt_thick) - dmin(flush_total / rho_l, CL(melt_thick));
 
   // top -> bottom: split into vertical / horizontal parts, vertical mass_transfer (fl_m(k+1) = -flush_v(k) <= 0),
   // horizontal loss of every layer goes to layer N_active
@@ -2287,14 +2354,14 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
   } else if (phi_N > psi_s_min && bf == 1) {
     for (int tr = nt - 1; tr >= -1; --tr) bottom_growth<K>(c, x, tr);
   } else if (th1 > 1.5 * thick_0) {
-    CL(melt_out3) = CL(melt_out3) - th1;
+    GS(MELT_OUT3) = GS(MELT_OUT3) - th1;
     for (int tr = nt - 1; tr >= -1; --tr) top_grow<K>(c, x, tr);
-    CL(melt_out3) = CL(melt_out3) + LAY(SAMSIM_A_THICK, 1);
+    GS(MELT_OUT3) = GS(MELT_OUT3) + LAY(SAMSIM_A_THICK, 1);
   } else if (th1 < 0.5 * thick_0) {
-    CL(melt_out3) = CL(melt_out3) - th1;
+    GS(MELT_OUT3) = GS(MELT_OUT3) - th1;
     for (int tr = nt - 1; tr >= -1; --tr) top_melt<K>(c, x, tr);
     if (c.status) return;
-    CL(melt_out3) = CL(melt_out3) + LAY(SAMSIM_A_THICK, 1);
+    GS(MELT_OUT3) = GS(MELT_OUT3) + LAY(SAMSIM_A_THICK, 1);
   }
 }
 
@@ -2303,7 +2370,7 @@ __device__ RARE void layer_dynamics(Col &c, const Ctx &x) {
 template <class K>
 __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double time) {
   const samsim_config &g = x.p->cfg;
-  if (c.Na > 1) CL(freeboard) = func_freeboard<K>(c, x); else CL(freeboard) = 0.0;
+  if (c.Na > 1) GS(FREEBOARD) = func_freeboard<K>(c, x); else GS(FREEBOARD) = 0.0;
   if (CFG(grav_flag) == 2) {
     if (CL(grav_drain) == 0.0) CL(grav_temp) = 0.0; else CL(grav_temp) = CL(grav_temp) / CL(grav_drain);
     CL(grav_salt) = CL(grav_salt) / g.time_out;
@@ -2328,16 +2395,16 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     }
     gdouble *o = x.out_scal + oc;
 #define OUT(idx, v) o[(size_t)(idx) * on] = (v)
-    OUT(SAMSIM_S_M_SNOW, c.m_snow); OUT(SAMSIM_S_H_ABS_SNOW, c.H_abs_snow); OUT(SAMSIM_S_S_ABS_SNOW, c.S_abs_snow);
-    OUT(SAMSIM_S_THICK_SNOW, c.thick_snow); OUT(SAMSIM_S_PSI_S_SNOW, c.psi_s_snow); OUT(SAMSIM_S_PSI_L_SNOW, c.psi_l_snow);
-    OUT(SAMSIM_S_PSI_G_SNOW, c.psi_g_snow); OUT(SAMSIM_S_T_SNOW, c.T_snow); OUT(SAMSIM_S_PHI_S, c.phi_s);
+    OUT(SAMSIM_S_M_SNOW, CL(m_snow)); OUT(SAMSIM_S_H_ABS_SNOW, CL(H_abs_snow)); OUT(SAMSIM_S_S_ABS_SNOW, GS(S_ABS_SNOW));
+    OUT(SAMSIM_S_THICK_SNOW, CL(thick_snow)); OUT(SAMSIM_S_PSI_S_SNOW, CL(psi_s_snow)); OUT(SAMSIM_S_PSI_L_SNOW, GS(PSI_L_SNOW));
+    OUT(SAMSIM_S_PSI_G_SNOW, GS(PSI_G_SNOW)); OUT(SAMSIM_S_T_SNOW, CL(T_snow)); OUT(SAMSIM_S_PHI_S, GS(PHI_S));
     OUT(SAMSIM_S_T_TOP, CL(T_top)); OUT(SAMSIM_S_MELT_THICK, CL(melt_thick)); OUT(SAMSIM_S_T2M, CL(T2m));
     OUT(SAMSIM_S_LIQUID_PRECIP, CL(liquid_precip)); OUT(SAMSIM_S_SOLID_PRECIP, CL(solid_precip)); OUT(SAMSIM_S_FL_Q_BOTTOM, c.fl_q_bottom);
     OUT(SAMSIM_S_GRAV_DRAIN, CL(grav_drain)); OUT(SAMSIM_S_GRAV_SALT, CL(grav_salt)); OUT(SAMSIM_S_GRAV_TEMP, CL(grav_temp));
-    OUT(SAMSIM_S_MELT_OUT1, CL(melt_out1)); OUT(SAMSIM_S_MELT_OUT2, CL(melt_out2)); OUT(SAMSIM_S_MELT_OUT3, CL(melt_out3));
-    OUT(SAMSIM_S_MELT_ERR, CL(melt_err)); OUT(SAMSIM_S_FREEBOARD, CL(freeboard)); OUT(SAMSIM_S_T_FREEZE, CL(T_freeze));
+    OUT(SAMSIM_S_MELT_OUT1, GS(MELT_OUT1)); OUT(SAMSIM_S_MELT_OUT2, GS(MELT_OUT2)); OUT(SAMSIM_S_MELT_OUT3, GS(MELT_OUT3));
+    OUT(SAMSIM_S_MELT_ERR, GS(MELT_ERR)); OUT(SAMSIM_S_FREEBOARD, GS(FREEBOARD)); OUT(SAMSIM_S_T_FREEZE, GS(T_FREEZE));
     OUT(SAMSIM_S_ALBEDO, CL(albedo)); OUT(SAMSIM_S_FL_SW, CL(fl_sw)); OUT(SAMSIM_S_FL_LW, CL(fl_lw));
-    OUT(SAMSIM_S_MELT_THICK_SNOW, c.melt_thick_snow); OUT(SAMSIM_S_FL_Q_SNOW, CL(fl_Q_snow));
+    OUT(SAMSIM_S_MELT_THICK_SNOW, CL(melt_thick_snow)); OUT(SAMSIM_S_FL_Q_SNOW, CL(fl_Q_snow));
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
     OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? CL(fl_lw) + 0.0 + 0.0
@@ -2355,7 +2422,7 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     }
   }
   CL(grav_drain) = 0.0; CL(grav_salt) = 0.0; CL(grav_temp) = 0.0;
-  CL(melt_out1) = 0.0; CL(melt_out2) = 0.0; CL(melt_out3) = 0.0;
+  GS(MELT_OUT1) = 0.0; GS(MELT_OUT2) = 0.0; GS(MELT_OUT3) = 0.0;
   (void)time;
 }
 
@@ -2480,16 +2547,16 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
       if (c.status) return;
     }
     // flooding, mo_grotz.f90:428-445
-    if (Na > 1 && CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0) {
+    if (Na > 1 && CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0) {
       // func_freeboard's "snow underwater" branch (mo_functions.f90:96-101) needs only the buoyancy totals, which S1
       // and P2 have accumulated; a non-negative freeboard is not read here and every later reader re-evaluates it
       const double buoy = c.buoy_s * (rho_l - rho_s) + c.buoy_g * rho_l;
-      if (c.m_snow > buoy) {
-        CL(freeboard) = (buoy - c.m_snow) / rho_l;
-        if (CL(freeboard) < 0.0 && CFG(flood_flag) == 2) {
+      if (CL(m_snow) > buoy) {
+        GS(FREEBOARD) = (buoy - CL(m_snow)) / rho_l;
+        if (GS(FREEBOARD) < 0.0 && CFG(flood_flag) == 2) {
           flood<K>(c, x);
           if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
-        } else if (K::general && CFG(flood_flag) == 3 && CL(freeboard) < neg_free) {
+        } else if (K::general && CFG(flood_flag) == 3 && GS(FREEBOARD) < neg_free) {
           flood_simple<K>(c, x);
           if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
         }
@@ -2580,9 +2647,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // The fused down sweep covers the common step.  The reference's order is kept by the unfused path whenever something
   // sits between expulsion and gravity drainage: the output block, thin-snow coupling, a possible flooding event
   // (decided from SUM(psi_g*thick) AFTER expulsion_flux: m_snow above the solid-only buoyancy is treated as possible).
-  const bool coupling = (c.m_snow > 0.0 && c.thick_snow < g.thick_min);
-  const bool flood_possible = (CFG(flood_flag) > 1 && c.m_snow > 0.0 && CFG(freeboard_snow_flag) == 0 &&
-                               c.m_snow > c.buoy_s * (rho_l - rho_s));
+  const bool coupling = (CL(m_snow) > 0.0 && CL(thick_snow) < g.thick_min);
+  const bool flood_possible = (CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0 &&
+                               CL(m_snow) > c.buoy_s * (rho_l - rho_s));
   const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2)
@@ -2646,10 +2713,10 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   if (c.status) return;
 
   // snow thermodynamics again, mo_grotz.f90:603-625
-  const double melt_thick_snow_old = c.melt_thick_snow;
+  const double melt_thick_snow_old = CL(melt_thick_snow);
   snow_block<K>(c, x);
   if (c.status) return;
-  c.melt_thick_snow = melt_thick_snow_old + c.melt_thick_snow;
+  CL(melt_thick_snow) = melt_thick_snow_old + CL(melt_thick_snow);
 
   // flushing preparations, mo_grotz.f90:632-664
   bool fb_valid = false;
@@ -2657,39 +2724,40 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // boundflux_flag 3 (:649-663) runs the same block on the air temperature instead of the surface temperature
     const bool lab = K::general && CFG(boundflux_flag) == 3;
     const double T_surf = lab ? CL(T2m) : CL(T_top);
-    CL(T_freeze) = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+    const double T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+    GS(T_FREEZE) = T_freeze;
     CL(melt_thick) = 0.0;
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
-    if (psi_s1 < psi_s_top_min || T_surf >= CL(T_freeze)) {
+    if (psi_s1 < psi_s_top_min || T_surf >= T_freeze) {
       if (!c.psi_full) STOPC(9001, 0);
-      CL(freeboard) = func_freeboard<K>(c, x);
+      GS(FREEBOARD) = func_freeboard<K>(c, x);
       fb_valid = true;
-      if (CL(freeboard) > 0.0000000000001) {
+      if (GS(FREEBOARD) > 0.0000000000001) {
         double thick1 = LAY(SAMSIM_A_THICK, 1);
         const double thick1_in = thick1;
         double melt_thick = 0.0;
-        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), CL(T_freeze), T_surf, CL(fl_Q1),
-                       c.thick_snow, g.dt, melt_thick, thick1, g.thick_min);
+        sub_melt_thick(LAY(SAMSIM_A_PSI_L, 1), psi_s1, LAY(SAMSIM_A_PSI_G, 1), LAY(SAMSIM_A_T, 1), T_freeze, T_surf, CL(fl_Q1),
+                       CL(thick_snow), g.dt, melt_thick, thick1, g.thick_min);
         CL(melt_thick) = melt_thick;
         if (lab) CL(melt_thick) = dmax(CL(melt_thick), 0.0);
-        if (c.thick_snow >= g.thick_min / 100.0 && CL(melt_thick) > 0.00000000001 && c.melt_thick_snow == 0.0) {
+        if (CL(thick_snow) >= g.thick_min / 100.0 && CL(melt_thick) > 0.00000000001 && CL(melt_thick_snow) == 0.0) {
           // sub_melt_snow, mo_functions.f90:443-474
           double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1);
-          const double shift = 1.0 / dmax(c.psi_g_snow, 0.01) * CL(melt_thick);
-          if (shift >= c.thick_snow) {
-            CL(melt_thick) = CL(melt_thick) - c.thick_snow * c.psi_g_snow;
-            H_abs = H_abs + c.H_abs_snow;
-            m = m + c.m_snow;
-            thick1 = thick1 + (1.0 - c.psi_g_snow) * c.thick_snow;
-            c.thick_snow = 0.0; c.m_snow = 0.0; c.H_abs_snow = 0.0;
+          const double shift = 1.0 / dmax(GS(PSI_G_SNOW), 0.01) * CL(melt_thick);
+          if (shift >= CL(thick_snow)) {
+            CL(melt_thick) = CL(melt_thick) - CL(thick_snow) * GS(PSI_G_SNOW);
+            H_abs = H_abs + CL(H_abs_snow);
+            m = m + CL(m_snow);
+            thick1 = thick1 + (1.0 - GS(PSI_G_SNOW)) * CL(thick_snow);
+            CL(thick_snow) = 0.0; CL(m_snow) = 0.0; CL(H_abs_snow) = 0.0;
           } else {
-            H_abs = H_abs + shift / c.thick_snow * c.H_abs_snow;
-            c.H_abs_snow = c.H_abs_snow - shift / c.thick_snow * c.H_abs_snow;
-            m = m + shift / c.thick_snow * c.m_snow;
-            c.m_snow = c.m_snow - shift / c.thick_snow * c.m_snow;
+            H_abs = H_abs + shift / CL(thick_snow) * CL(H_abs_snow);
+            CL(H_abs_snow) = CL(H_abs_snow) - shift / CL(thick_snow) * CL(H_abs_snow);
+            m = m + shift / CL(thick_snow) * CL(m_snow);
+            CL(m_snow) = CL(m_snow) - shift / CL(thick_snow) * CL(m_snow);
             thick1 = thick1 + shift - CL(melt_thick);
-            c.thick_snow = c.thick_snow - shift;
+            CL(thick_snow) = CL(thick_snow) - shift;
             CL(melt_thick) = 0.0;
           }
           LAY(SAMSIM_A_H_ABS, 1) = H_abs;
@@ -2704,23 +2772,24 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // flushing, mo_grotz.f90:670-737
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
-                               CL(melt_thick) + c.melt_thick_snow > 0.000000000001);
+                               CL(melt_thick) + CL(melt_thick_snow) > 0.000000000001);
   if (flush_possible && !c.psi_full) STOPC(9001, 0);
-  if (flush_possible && !fb_valid) CL(freeboard) = func_freeboard<K>(c, x);
-  CL(melt_out1) = CL(melt_out1) + CL(melt_thick);
-  CL(melt_out2) = CL(melt_out2) + c.melt_thick_snow;
-  CL(melt_thick) = CL(melt_thick) + c.melt_thick_snow;
-  if (c.melt_thick_snow > 0.0) {
-    const double mts = c.melt_thick_snow;
+  if (flush_possible && !fb_valid) GS(FREEBOARD) = func_freeboard<K>(c, x);
+  // (the accumulators sit in the scalar block: x + 0 is x, so nothing is read or written while nothing melts)
+  if (CL(melt_thick) != 0.0) GS(MELT_OUT1) = GS(MELT_OUT1) + CL(melt_thick);
+  if (CL(melt_thick_snow) != 0.0) GS(MELT_OUT2) = GS(MELT_OUT2) + CL(melt_thick_snow);
+  CL(melt_thick) = CL(melt_thick) + CL(melt_thick_snow);
+  if (CL(melt_thick_snow) > 0.0) {
+    const double mts = CL(melt_thick_snow);
     double H1 = LAY(SAMSIM_A_H_ABS, 1), S1 = LAY(SAMSIM_A_S_ABS, 1), m1 = LAY(SAMSIM_A_M, 1);
-    H1 = H1 + mts * rho_l * c_l * c.T_snow;
-    S1 = S1 + mts * rho_l * S_br_clamped(x.salt, c.T_snow, c.S_abs_snow / c.m_snow);
+    H1 = H1 + mts * rho_l * c_l * CL(T_snow);
+    S1 = S1 + mts * rho_l * S_br_clamped(x.salt, CL(T_snow), GS(S_ABS_SNOW) / CL(m_snow));
     m1 = m1 + mts * rho_l;
     LAY(SAMSIM_A_H_ABS, 1) = H1; LAY(SAMSIM_A_S_ABS, 1) = S1; LAY(SAMSIM_A_M, 1) = m1;
     LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) + mts;
     LAY(SAMSIM_A_S_BU, 1) = S1 / m1;
   }
-  if (flush_possible && CL(freeboard) > 0.001) {
+  if (flush_possible && GS(FREEBOARD) > 0.001) {
     if (CL(melt_thick) > 0.000000000001) {
       if (K::general && CFG(flush_flag) == 4) {  // melt water simply leaves the top layer, mo_grotz.f90:704-713
         const double T1 = LAY(SAMSIM_A_T, 1), m1 = LAY(SAMSIM_A_M, 1);
@@ -2729,13 +2798,13 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
         LAY(SAMSIM_A_THICK, 1) = LAY(SAMSIM_A_THICK, 1) - CL(melt_thick);
         LAY(SAMSIM_A_M, 1) = m1 - CL(melt_thick) * rho_l;
       } else if (K::general && CFG(flush_flag) == 6) {  // :729-733
-        if (c.thick_snow < g.thick_0) {
+        if (CL(thick_snow) < g.thick_0) {
           flush4<K>(c, x);
           c.flags |= COLF_DIRTY;
           if (c.status) return;
         }
       } else {
-        if (c.melt_thick_snow > 0.0) CL(freeboard) = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
+        if (CL(melt_thick_snow) > 0.0) GS(FREEBOARD) = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
         flush3<K>(c, x);
         c.flags |= COLF_DIRTY;
         if (c.status) return;
@@ -2774,7 +2843,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 
   ST_MARK(ST_POST);
   // health check, mo_grotz.f90:808-819 (negative S_abs is clamped element-wise at the next sweep)
-  if (c.min_psi_s < 0.0) STOPC(1337, 0);
+  if (c.neg_psi) STOPC(1337, 0);
   if (c.Na == 1) {
     const double v = LAY(SAMSIM_A_S_ABS, 1);
     if (v < 0.0) LAY(SAMSIM_A_S_ABS, 1) = 0.0;
@@ -2837,16 +2906,13 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.status = status[col];
   c.err_layer = err_layer[col];
   c.err_step = err_step[col];
-  c.frad = 0.0; c.min_psi_s = 0.0; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
+  c.frad = 0.0; c.neg_psi = false; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
   c.spec = (gdouble *)spec;
   const size_t nc = (size_t)p.ncol;
   double *sc = scal + col;
 #define SLOAD(field, idx) c.field = sc[(size_t)(idx) * nc]
-  SLOAD(m_snow, SAMSIM_S_M_SNOW); SLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SLOAD(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
-  SLOAD(thick_snow, SAMSIM_S_THICK_SNOW); SLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SLOAD(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
-  SLOAD(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SLOAD(T_snow, SAMSIM_S_T_SNOW); SLOAD(phi_s, SAMSIM_S_PHI_S);
-  SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM); SLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
+  SLOAD(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
 #undef SLOAD
   // row flags of the Rayleigh-number array (Ctx::rflag): at the start of a launch every row is valid (the last up sweep of a
   // launch stores all rows, as does samsim_set_state's full first sweep)
@@ -2858,12 +2924,12 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.ld = (ldouble *)lds_scal + threadIdx.x;
 #define LLOAD(field, idx) CL(field) = sc[(size_t)(idx) * nc]
   LLOAD(grav_drain, SAMSIM_S_GRAV_DRAIN); LLOAD(grav_salt, SAMSIM_S_GRAV_SALT); LLOAD(grav_temp, SAMSIM_S_GRAV_TEMP);
-  LLOAD(melt_out1, SAMSIM_S_MELT_OUT1); LLOAD(melt_out2, SAMSIM_S_MELT_OUT2); LLOAD(melt_out3, SAMSIM_S_MELT_OUT3);
-  LLOAD(melt_err, SAMSIM_S_MELT_ERR); LLOAD(freeboard, SAMSIM_S_FREEBOARD); LLOAD(T_freeze, SAMSIM_S_T_FREEZE);
   LLOAD(T_top, SAMSIM_S_T_TOP); LLOAD(fl_Q_snow, SAMSIM_S_FL_Q_SNOW); LLOAD(melt_thick, SAMSIM_S_MELT_THICK);
   CL(fl_Q1) = 0.0;
   LLOAD(albedo, SAMSIM_S_ALBEDO); LLOAD(fl_sw, SAMSIM_S_FL_SW); LLOAD(fl_lw, SAMSIM_S_FL_LW);
   LLOAD(T2m, SAMSIM_S_T2M); LLOAD(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LLOAD(solid_precip, SAMSIM_S_SOLID_PRECIP);
+  LLOAD(m_snow, SAMSIM_S_M_SNOW); LLOAD(H_abs_snow, SAMSIM_S_H_ABS_SNOW); LLOAD(thick_snow, SAMSIM_S_THICK_SNOW);
+  LLOAD(T_snow, SAMSIM_S_T_SNOW); LLOAD(psi_s_snow, SAMSIM_S_PSI_S_SNOW); LLOAD(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
 #undef LLOAD
 
   // uniform clock (mo_data: time, i, n_time_out, time_counter) evolves identically in every lane
@@ -2888,7 +2954,16 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
     if (!c.status) {
       c.step = step;
       work_done += c.Na;
-      column_step<K>(c, x, col, time, tc, out_step, next_out, s + 1 == p.nsteps);
+      // The lane's column index is the same in every step, so every address formed from it -- some forty scalar-block, hand-over
+      // and top-layer words per step -- is invariant in this loop: left alone the optimiser computes all of them once, as 64-bit
+      // per-lane addresses, keeps them for the whole launch and, having no registers for them, spills them at the start and
+      // reloads one from scratch memory (= HBM) at every use.  Passing the index through an empty asm makes them values of the
+      // step: each is formed where it is used (two or three vector instructions) and nothing is carried.
+      long long col_step = col;
+#if SAMSIM_LAUNDER_COL
+      asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(col_step));
+#endif
+      column_step<K>(c, x, col_step, time, tc, out_step, next_out, s + 1 == p.nsteps);
     }
     time = time + p.cfg.dt;
     step = step + 1;
@@ -2901,18 +2976,15 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   err_step[col] = c.err_step;
   work[col] += work_done;
 #define SSTORE(field, idx) sc[(size_t)(idx) * nc] = c.field
-  SSTORE(m_snow, SAMSIM_S_M_SNOW); SSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); SSTORE(S_abs_snow, SAMSIM_S_S_ABS_SNOW);
-  SSTORE(thick_snow, SAMSIM_S_THICK_SNOW); SSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); SSTORE(psi_l_snow, SAMSIM_S_PSI_L_SNOW);
-  SSTORE(psi_g_snow, SAMSIM_S_PSI_G_SNOW); SSTORE(T_snow, SAMSIM_S_T_SNOW); SSTORE(phi_s, SAMSIM_S_PHI_S);
-  SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM); SSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
+  SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
 #undef SSTORE
 #define LSTORE(field, idx) sc[(size_t)(idx) * nc] = CL(field)
   LSTORE(grav_drain, SAMSIM_S_GRAV_DRAIN); LSTORE(grav_salt, SAMSIM_S_GRAV_SALT); LSTORE(grav_temp, SAMSIM_S_GRAV_TEMP);
-  LSTORE(melt_out1, SAMSIM_S_MELT_OUT1); LSTORE(melt_out2, SAMSIM_S_MELT_OUT2); LSTORE(melt_out3, SAMSIM_S_MELT_OUT3);
-  LSTORE(melt_err, SAMSIM_S_MELT_ERR); LSTORE(freeboard, SAMSIM_S_FREEBOARD); LSTORE(T_freeze, SAMSIM_S_T_FREEZE);
   LSTORE(albedo, SAMSIM_S_ALBEDO); LSTORE(fl_sw, SAMSIM_S_FL_SW); LSTORE(fl_lw, SAMSIM_S_FL_LW);
   LSTORE(T2m, SAMSIM_S_T2M); LSTORE(liquid_precip, SAMSIM_S_LIQUID_PRECIP); LSTORE(solid_precip, SAMSIM_S_SOLID_PRECIP);
   LSTORE(T_top, SAMSIM_S_T_TOP); LSTORE(fl_Q_snow, SAMSIM_S_FL_Q_SNOW); LSTORE(melt_thick, SAMSIM_S_MELT_THICK);
+  LSTORE(m_snow, SAMSIM_S_M_SNOW); LSTORE(H_abs_snow, SAMSIM_S_H_ABS_SNOW); LSTORE(thick_snow, SAMSIM_S_THICK_SNOW);
+  LSTORE(T_snow, SAMSIM_S_T_SNOW); LSTORE(psi_s_snow, SAMSIM_S_PSI_S_SNOW); LSTORE(melt_thick_snow, SAMSIM_S_MELT_THICK_SNOW);
 #undef LSTORE
   sc[(size_t)SAMSIM_S_S_BU_BOTTOM * nc] = x.S_bu_bottom;
   // fl_rest = fl_lw + sensible + latent (both zero) with the forcing tables, mo_heat_fluxes.f90:112
