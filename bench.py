@@ -228,6 +228,8 @@ def stage_windows(g, cfg, args, forcing):
     from samsim_amd.capi import State
     out = {}
     stages = [("day0_open_water", None)] + [(f"day{d}", f"sheba_ensemble_{args.nlayer}_day{d}.npz") for d in (75, 150, 250, 300, 345, 360)]
+    if args.stages:
+        stages = [st for st in stages if st[0] in args.stages.split(",")]
     for name, fixture in stages:
         if fixture is None:
             _, st0 = tcs.testcase4(1, nlayer=int(cfg.nlayer), n_top=int(cfg.n_top), n_bottom=int(cfg.n_bottom))
@@ -273,6 +275,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the stage windows (open water ... melt season)")
     ap.add_argument("--extra-launches", type=int, default=2)
+    ap.add_argument("--stages", default=None, help="comma-separated subset of the stage windows (day0_open_water, day75, ... day360)")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, let them meet (barrier + reductions) and report the sharding without touching a GPU")
     ap.add_argument("--device-map", default=None,

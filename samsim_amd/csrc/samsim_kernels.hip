@@ -52,7 +52,8 @@ namespace {
 #if SAMSIM_STAMPS
 enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_TAIL,
        CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
-       CT_DRAIN_LANE, CT_DIRTY, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B };
+       CT_DRAIN_LANE, CT_DIRTY, CT_L_COUPLING, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B,
+       CT_L_FLOODP = 25, CT_L_IRREG, CT_L_DIRTY, CT_L_UNFUSED, CT_L_FLUSH3, CT_L_REGRID, CT_L_FREEBOARD };
 struct Stamps {
   unsigned long long *acc;   // [32] in LDS, one block = one wave
   unsigned long long t0;
@@ -182,7 +183,9 @@ enum lds_slot {
 // Per-column scalars that the common step does not touch (melt-water accumulators, freeboard, T_freeze, the snow's salt and the
 // volume fractions only snow_thermo itself reads) are read and written IN PLACE in the scalar block: GS(FREEBOARD) = slot
 // SAMSIM_S_FREEBOARD of this lane's column.  19 LDS slots are what 16 one-wave workgroups per CU leave room for.
-#define GS(IDX) x.scal[(size_t)(SAMSIM_S_##IDX) * c.ncol + c.col]
+// (scalar base + 32-bit byte offset, like LAY: slot * bytes-per-row + this lane's column; 38 slots of at most 4 GiB / nlayer)
+#define GSI(idx) (*(gdouble *)((gchar *)x.scal + (size_t)(unsigned)((unsigned)(idx) * c.rstride + c.coff)))
+#define GS(IDX) GSI(SAMSIM_S_##IDX)
 
 struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S_br), mo_thermo_functions.f90:308-414
   double c2, c3, c4, d2, d3, d4;
@@ -255,6 +258,16 @@ struct Col {
 // SAMSIM_DUNROLL: the interior loop of the fused down sweep handles two layers per trip (see there)
 #ifndef SAMSIM_DUNROLL
 #define SAMSIM_DUNROLL 1
+#endif
+// RARE_CHUNK: the sweeps of the melt season (flushing, freeboard, the unfused order of a step with thin snow or possible flooding)
+// walk a column with a per-lane trip count and little arithmetic per layer; with a row requested where it is used every
+// iteration waits a full memory latency (2 us under load against 0.1-0.5 us of work).  They request RARE_CHUNK rows at a time
+// -- unconditionally, from a clamped row beyond the column's last layer -- and then work through them in order.
+#ifndef RARE_CHUNK
+#define RARE_CHUNK 8
+#endif
+#ifndef SAMSIM_PATH_MODE
+#define SAMSIM_PATH_MODE 0
 #endif
 // SAMSIM_LAUNDER_COL: the column index is re-declared to the optimiser at every time step (see samsim_step_kernel)
 #ifndef SAMSIM_LAUNDER_COL
@@ -568,6 +581,7 @@ struct Ctx {
   // whole array is wanted: output, end of a launch), the down sweeps load only those rows and take 0 elsewhere.
   lu64 *rflag;
   bool ray_rows_all;   // this up sweep stores every row
+
 #if SAMSIM_STAMPS
   mutable Stamps st;
 #endif
@@ -607,10 +621,18 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
   double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? CL(m_snow) : 0.0;
   double A = 0.0, G = 0.0;
-  for (int k = 1; k <= Na; ++k) {
-    double th = LAY(SAMSIM_A_THICK, k);
-    A += LAY(SAMSIM_A_PSI_S, k) * th;
-    G += LAY(SAMSIM_A_PSI_G, k) * th;
+  // (rows are requested a chunk at a time -- see RARE_CHUNK -- and summed in the reference's order)
+  for (int k0 = 1; k0 <= Na; k0 += RARE_CHUNK) {
+    double th_[RARE_CHUNK], ps_[RARE_CHUNK], pg_[RARE_CHUNK];
+#pragma unroll
+    for (int i = 0; i < RARE_CHUNK; ++i) {
+      const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
+      th_[i] = LAY(SAMSIM_A_THICK, kk); ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
+    }
+#pragma unroll
+    for (int i = 0; i < RARE_CHUNK; ++i) {
+      if (k0 + i <= Na) { A += ps_[i] * th_[i]; G += pg_[i] * th_[i]; }
+    }
   }
   double buoy = A * (rho_l - rho_s) + G * rho_l;
   double freeboard;
@@ -619,17 +641,29 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   } else {
     double Ap = 0.0, Gp = 0.0, Mp = 0.0, Tp = 0.0;  // prefix sums over 1..k-1
     double test2 = 0.0, mk = 0.0, thk = 1.0;
-    int k = 0;
-    for (;;) {
-      ++k;
-      mk = LAY(SAMSIM_A_M, k);
-      thk = LAY(SAMSIM_A_THICK, k);
-      double a = LAY(SAMSIM_A_PSI_S, k) * thk, g = LAY(SAMSIM_A_PSI_G, k) * thk;
-      // buoyancy of the layers below k, mass of layers 1..k
-      test2 = (k == Na) ? 0.0 : ((A - (Ap + a)) * (rho_l - rho_s) + (G - (Gp + g)) * rho_l);
-      double test1 = (Mp + mk) + snowmass;
-      if (!(test1 < test2) || k >= Na) break;
-      Ap += a; Gp += g; Mp += mk; Tp += thk;
+    bool done = false;
+    for (int k0 = 1; !done; k0 += RARE_CHUNK) {
+      double m_[RARE_CHUNK], th_[RARE_CHUNK], ps_[RARE_CHUNK], pg_[RARE_CHUNK];
+#pragma unroll
+      for (int i = 0; i < RARE_CHUNK; ++i) {
+        const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
+        m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = LAY(SAMSIM_A_THICK, kk);
+        ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
+      }
+#pragma unroll
+      for (int i = 0; i < RARE_CHUNK; ++i) {
+        if (!done) {
+          const int k = k0 + i;
+          mk = m_[i];
+          thk = th_[i];
+          double a = ps_[i] * thk, g = pg_[i] * thk;
+          // buoyancy of the layers below k, mass of layers 1..k
+          test2 = (k == Na) ? 0.0 : ((A - (Ap + a)) * (rho_l - rho_s) + (G - (Gp + g)) * rho_l);
+          double test1 = (Mp + mk) + snowmass;
+          if (!(test1 < test2) || k >= Na) done = true;
+          else { Ap += a; Gp += g; Mp += mk; Tp += thk; }
+        }
+      }
     }
     double test1 = Mp + snowmass;
     freeboard = test2 - test1 + (rho_l - mk / thk) * thk;
@@ -928,17 +962,24 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
-  // loads one layer ahead of the arithmetic, as in the fused sweeps
-  double H_n = LAY(SAMSIM_A_H_ABS, Na), m_n = LAY(SAMSIM_A_M, Na), th_n = LAY(SAMSIM_A_THICK, Na), S_n = LAY(SAMSIM_A_S_ABS, Na);
+  // operands requested two layers ahead of the arithmetic, unconditionally and from a clamped row, as in sweep_up_fused
+  struct L4 { double H, m, th, S; };
+  auto ld = [&](int j) -> L4 {
+    L4 r;
+    r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.th = LAY(SAMSIM_A_THICK, j); r.S = LAY(SAMSIM_A_S_ABS, j);
+    return r;
+  };
+  L4 cur = ld(Na), nxt = ld(Na >= 2 ? Na - 1 : 1), nn = nxt;
   bool regular = true;
   const double th_mid_rule = LAY(SAMSIM_A_THICK, g.n_top + 1);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
-    const double H_abs = H_n, m = m_n, thick = th_n;
+    nn = ld(k >= 3 ? k - 2 : 1);
+    const double H_abs = cur.H, m = cur.m, thick = cur.th;
     if (k >= 2 && thick != thick_by_rule(k, g.n_top, g.n_middle, th_mid_rule, g.thick_0)) regular = false;
-    double S_abs = S_n;
-    if (k > 1) { H_n = LAY(SAMSIM_A_H_ABS, k - 1); m_n = LAY(SAMSIM_A_M, k - 1); th_n = LAY(SAMSIM_A_THICK, k - 1); S_n = LAY(SAMSIM_A_S_ABS, k - 1); }
+    double S_abs = cur.S;
+    cur = nxt; nxt = nn;
     if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
       S_abs = 0.0;
       LAY(SAMSIM_A_S_ABS, k) = S_abs;
@@ -999,19 +1040,25 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   double flm_k = 0.0;  // fl_m(k)
   double buoy_g = 0.0;
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
-  // loads one layer ahead of the arithmetic, as in the fused sweeps
-  double m_n = LAY(SAMSIM_A_M, 1), th_n = LAY(SAMSIM_A_THICK, 1), T_n = LAY(SAMSIM_A_T, 1), H_n = LAY(SAMSIM_A_H_ABS, 1),
-         S_n = LAY(SAMSIM_A_S_ABS, 1);
-  for (int k = 1; k <= Na; ++k) {
-    double m = m_n;
-    const double thick = th_n;
-    // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
-    const double T = T_n, H_abs_in = H_n;
-    double S_abs = S_n;
-    if (k < Na) {
-      m_n = LAY(SAMSIM_A_M, k + 1); th_n = LAY(SAMSIM_A_THICK, k + 1); T_n = LAY(SAMSIM_A_T, k + 1);
-      H_n = LAY(SAMSIM_A_H_ABS, k + 1); S_n = LAY(SAMSIM_A_S_ABS, k + 1);
+  // rows are requested a chunk at a time (see RARE_CHUNK)
+  constexpr int CH = RARE_CHUNK / 2;
+  for (int k0 = 1; k0 <= Na; k0 += CH) {
+    double m_[CH], th_[CH], T_[CH], H_[CH], S_[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
+      m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = LAY(SAMSIM_A_THICK, kk); T_[i] = LAY(SAMSIM_A_T, kk);
+      H_[i] = LAY(SAMSIM_A_H_ABS, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk);
     }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+    const int k = k0 + i;
+    if (k <= Na) {
+    double m = m_[i];
+    const double thick = th_[i];
+    // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
+    const double T = T_[i], H_abs_in = H_[i];
+    double S_abs = S_[i];
     double S_bu_in, H_in;
     per_mass(S_abs, H_abs_in, m, S_bu_in, H_in);
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
@@ -1056,6 +1103,8 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_S_BU, k) = S_abs / m;
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_k = flm_next;
+    }
+    }
   }
   c.buoy_g = buoy_g;
 }
@@ -1219,18 +1268,18 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
   int stop_layer = 0;
 
   struct L { double T, S_bu, S_abs, H_abs, flup, fdown; bool ch; };
-  double S_br_j = LAY(SAMSIM_A_S_BR, 1);  // S_br(j), prefetched one layer ahead
+  struct Ops { double T, S_bu, S_abs, H_abs, thick, S_br, S_br_below; };
 
   // drain(j): gravity-drainage loss of layer j (mo_grav_drain.f90:144-170) and fl_up(j)
-  auto drain = [&](int j) -> L {
+  auto drain = [&](int j, const Ops &o) -> L {
     L r;
-    r.T = LAY(SAMSIM_A_T, j);
-    r.S_bu = LAY(SAMSIM_A_S_BU, j);
-    r.S_abs = LAY(SAMSIM_A_S_ABS, j);
-    r.H_abs = LAY(SAMSIM_A_H_ABS, j);
+    r.T = o.T;
+    r.S_bu = o.S_bu;
+    r.S_abs = o.S_abs;
+    r.H_abs = o.H_abs;
     r.ch = false;
     r.fdown = 0.0;
-    const double thick = LAY(SAMSIM_A_THICK, j);
+    const double thick = o.thick;
     if (do_beer) {
       if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
       if (j == Na) c.frad = temp2 - temp2 * e;
@@ -1239,10 +1288,9 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     sum_before += r.S_abs;
     r.flup = cum;
     if (j <= Na - 1) {
-      const double S_br = S_br_j;
-      S_br_j = LAY(SAMSIM_A_S_BR, j + 1);
+      const double S_br = o.S_br;
       const double ray = ray_row_valid(c, x, j) ? LAY(SAMSIM_A_RAY, j) : 0.0;
-      if (ray > ray_crit && S_br > S_br_j) {
+      if (ray > ray_crit && S_br > o.S_br_below) {
         const double psi_s = LAY(SAMSIM_A_PSI_S, j), m = LAY(SAMSIM_A_M, j);
         if (psi_s > 0.001 && r.S_abs / m > 0.1) {
           const double psi_l = LAY(SAMSIM_A_PSI_L, j);
@@ -1264,38 +1312,60 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     return r;
   };
 
-  L cur = drain(1), nxt = cur;
+  // Layer j is drained, then layer j-1 -- which now knows its neighbour below -- is finished: the reference's order.  The plain
+  // operands of a chunk of layers are requested together (see RARE_CHUNK); what only a draining layer reads is loaded there.
+  constexpr int CH = RARE_CHUNK / 2;
+  const int N = c.N;
+  L cur = {0, 0, 0, 0, 0, 0, false};
   double flup_prev = 0.0;  // fl_up(k-1) = fl_m(k)
-  for (int k = 1; k <= Na; ++k) {
-    double T_below, S_bu_below, SS_abs_below;
-    if (k < Na) {
-      nxt = drain(k + 1);
-      T_below = nxt.T; S_bu_below = nxt.S_bu; SS_abs_below = nxt.S_abs;
-    } else {
-      T_below = g.T_bottom; S_bu_below = x.S_bu_bottom; SS_abs_below = x.S_bu_bottom * 2000.0;
+  for (int j0 = 1; j0 <= Na + 1; j0 += CH) {
+    double T_[CH], Sbu_[CH], S_[CH], H_[CH], th_[CH], Sbr_[CH + 1];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int kk = (j0 + i <= N) ? j0 + i : N;
+      T_[i] = LAY(SAMSIM_A_T, kk); Sbu_[i] = LAY(SAMSIM_A_S_BU, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk);
+      H_[i] = LAY(SAMSIM_A_H_ABS, kk); th_[i] = LAY(SAMSIM_A_THICK, kk); Sbr_[i] = LAY(SAMSIM_A_S_BR, kk);
     }
-    if (cur.flup > 0.0) {  // fl_m(k+1) > 0: inflow from below
-      cur.H_abs = cur.H_abs + cur.flup * T_below * c_l;
-      cur.S_abs = cur.S_abs + dmin(cur.flup * S_br_clamped(s, T_below, S_bu_below), SS_abs_below);
-      cur.ch = true;
+    Sbr_[CH] = LAY(SAMSIM_A_S_BR, (j0 + CH <= N) ? j0 + CH : N);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int j = j0 + i;
+      if (j <= Na + 1) {
+        L nxt = cur;
+        if (j <= Na) nxt = drain(j, Ops{T_[i], Sbu_[i], S_[i], H_[i], th_[i], Sbr_[i], Sbr_[i + 1]});
+        if (j >= 2) {
+          const int k = j - 1;
+          double T_below, S_bu_below, SS_abs_below;
+          if (k < Na) {
+            T_below = nxt.T; S_bu_below = nxt.S_bu; SS_abs_below = nxt.S_abs;
+          } else {
+            T_below = g.T_bottom; S_bu_below = x.S_bu_bottom; SS_abs_below = x.S_bu_bottom * 2000.0;
+          }
+          if (cur.flup > 0.0) {  // fl_m(k+1) > 0: inflow from below
+            cur.H_abs = cur.H_abs + cur.flup * T_below * c_l;
+            cur.S_abs = cur.S_abs + dmin(cur.flup * S_br_clamped(s, T_below, S_bu_below), SS_abs_below);
+            cur.ch = true;
+          }
+          if (flup_prev > 0.0) {  // fl_m(k) > 0: outflow to the layer above
+            cur.H_abs = cur.H_abs - flup_prev * cur.T * c_l;
+            cur.S_abs = cur.S_abs - dmin(flup_prev * S_br_clamped(s, cur.T, cur.S_bu), cur.S_abs);
+            cur.ch = true;
+          }
+          if (k == Na) {
+            CL(grav_drain) = CL(grav_drain) + cur.flup;
+            if (CFG(grav_heat_flag) == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
+          }
+          if (cur.ch) {
+            LAY(SAMSIM_A_S_ABS, k) = cur.S_abs;
+            LAY(SAMSIM_A_H_ABS, k) = cur.H_abs;
+          }
+          if (HAS_BGC) { BFL(BFL_D, k) = cur.fdown; BFL(BFL_U, k) = cur.flup; }
+          minS = dmin(minS, cur.S_abs);
+          flup_prev = cur.flup;
+        }
+        cur = nxt;
+      }
     }
-    if (flup_prev > 0.0) {  // fl_m(k) > 0: outflow to the layer above
-      cur.H_abs = cur.H_abs - flup_prev * cur.T * c_l;
-      cur.S_abs = cur.S_abs - dmin(flup_prev * S_br_clamped(s, cur.T, cur.S_bu), cur.S_abs);
-      cur.ch = true;
-    }
-    if (k == Na) {
-      CL(grav_drain) = CL(grav_drain) + cur.flup;
-      if (CFG(grav_heat_flag) == 2) { cur.H_abs = cur.H_abs + heat_loss - cur.flup * c_l * g.T_bottom; cur.ch = true; }
-    }
-    if (cur.ch) {
-      LAY(SAMSIM_A_S_ABS, k) = cur.S_abs;
-      LAY(SAMSIM_A_H_ABS, k) = cur.H_abs;
-    }
-    if (HAS_BGC) { BFL(BFL_D, k) = cur.fdown; BFL(BFL_U, k) = cur.flup; }
-    minS = dmin(minS, cur.S_abs);
-    flup_prev = cur.flup;
-    cur = nxt;
   }
   CL(grav_salt) = CL(grav_salt) + sum_before;
   CL(grav_salt) = CL(grav_salt) - sum_after;
@@ -1349,7 +1419,7 @@ __device__ RARE void sweep_beer(Col &c, const Ctx &x, double beer0) {
 // balance); fl_Q(2) and the two energy sums are handed on in the column struct.
 template <class K>
 __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
-  const int Na = c.Na;
+  const int Na = c.Na, N = c.N;
   const double dt = x.p->cfg.dt;
   const double frad_dt = c.frad * dt;
   double esum = 0.0;
@@ -1358,19 +1428,34 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
     double T_up = LAY(SAMSIM_A_T, 1);
     double hr_up = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
     double flq_k = 0.0;   // fl_Q(k)
-    for (int k = 2; k <= Na; ++k) {
-      const double T = LAY(SAMSIM_A_T, k);
-      const double hr = LAY(SAMSIM_A_THICK, k) / (2.0 * (LAY(SAMSIM_A_PSI_S, k) * k_s + LAY(SAMSIM_A_PSI_L, k) * k_l));
-      const double flq = (T - T_up) / (hr_up + hr);
-      if (k == 2) c.flq2 = flq;
-      if (k >= 3) {   // layer k-1: both of its fluxes are known now
-        const double H_b = LAY(SAMSIM_A_H_ABS, k - 1);
-        double H_abs = H_b + (flq - flq_k) * dt;
-        H_abs = H_abs + frad_dt;
-        esum += H_b - H_abs;
-        LAY(SAMSIM_A_H_ABS, k - 1) = H_abs;
+    constexpr int CH = RARE_CHUNK / 2;   // five operands per layer (rows requested a chunk at a time, see RARE_CHUNK)
+    for (int k0 = 2; k0 <= Na; k0 += CH) {
+      double T_[CH], th_[CH], ps_[CH], pl_[CH], Hm_[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int kk = (k0 + i <= N) ? k0 + i : N;
+        T_[i] = LAY(SAMSIM_A_T, kk); th_[i] = LAY(SAMSIM_A_THICK, kk);
+        ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pl_[i] = LAY(SAMSIM_A_PSI_L, kk);
+        Hm_[i] = LAY(SAMSIM_A_H_ABS, kk - 1);    // layer k-1 (kk >= 2), finished when layer k's flux is known
       }
-      T_up = T; hr_up = hr; flq_k = flq;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int k = k0 + i;
+        if (k <= Na) {
+          const double T = T_[i];
+          const double hr = th_[i] / (2.0 * (ps_[i] * k_s + pl_[i] * k_l));
+          const double flq = (T - T_up) / (hr_up + hr);
+          if (k == 2) c.flq2 = flq;
+          if (k >= 3) {   // layer k-1: both of its fluxes are known now
+            const double H_b = Hm_[i];
+            double H_abs = H_b + (flq - flq_k) * dt;
+            H_abs = H_abs + frad_dt;
+            esum += H_b - H_abs;
+            LAY(SAMSIM_A_H_ABS, k - 1) = H_abs;
+          }
+          T_up = T; hr_up = hr; flq_k = flq;
+        }
+      }
     }
     const double H_b = LAY(SAMSIM_A_H_ABS, Na);   // bottom layer: fl_Q(N_active+1) = fl_q_bottom
     double H_abs = H_b + (c.fl_q_bottom - flq_k) * dt;
@@ -1712,7 +1797,7 @@ __device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double 
     const double a = (day - 164.0) / (double)47.9f, b = (day - 206.0) / (double)53.1f;
     CL(fl_sw) = 314.0 * exp(-0.5 * (a * a));
     if (day < 60.0 || day > 300.0) CL(fl_sw) = 0.0;
-    x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col] = 118.0 * exp(-0.5 * (b * b)) + 179.0;
+    GSI(SAMSIM_S_FL_REST) = 118.0 * exp(-0.5 * (b * b)) + 179.0;
   }
   const double pen = (CL(thick_snow) < g.thick_min) ? penetr : 0.0;
   return pen * (1.0 - CL(albedo)) * CL(fl_sw);
@@ -1762,7 +1847,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   }
   // boundflux_flag 2, mo_heat_fluxes.f90:91-195
   const double thick_min = g.thick_min;
-  const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? CL(fl_lw) + 0.0 + 0.0 : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col];
+  const double fl_rest = (!K::general || CFG(atmoflux_flag) == 2) ? CL(fl_lw) + 0.0 + 0.0 : GSI(SAMSIM_S_FL_REST);
   const double emi = (CL(thick_snow) < thick_min) ? emissivity_ice : emissivity_snow;
   const double pen = (CL(thick_snow) < thick_min) ? penetr : 0.0;
   double temp1;
@@ -1967,7 +2052,13 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   const double dt = g.dt;
   // horizontal flow length = total thickness (mo_flush.f90:104)
   double cnst = 0.0;
-  for (int k = 1; k <= Na; ++k) cnst += LAY(SAMSIM_A_THICK, k);
+  for (int k0 = 1; k0 <= Na; k0 += 2 * RARE_CHUNK) {   // (rows requested a chunk at a time, see RARE_CHUNK)
+    double th_[2 * RARE_CHUNK];
+#pragma unroll
+    for (int i = 0; i < 2 * RARE_CHUNK; ++i) th_[i] = LAY(SAMSIM_A_THICK, (k0 + i <= N) ? k0 + i : N);
+#pragma unroll
+    for (int i = 0; i < 2 * RARE_CHUNK; ++i) if (k0 + i <= Na) cnst += th_[i];
+  }
   cnst = cnst * para_flush_horiz;
   const double psi_l1 = LAY(SAMSIM_A_PSI_L, 1), thick1 = LAY(SAMSIM_A_THICK, 1), T1 = LAY(SAMSIM_A_T, 1);
   CL(melt_thick) = dmin(CL(melt_thick), psi_l1 * thick1);
@@ -1977,24 +2068,37 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   const double pfill = (CFG(snow_flush_flag) == 1) ? 0.0 : 1.0;
   for (int k = Na + 1; k <= N; ++k) LAY(SAMSIM_A_PERM, k) = pfill;
   double R_below = 0.0;  // R(k+1)
-  for (int k = Na; k >= 1; --k) {
-    const double thick = LAY(SAMSIM_A_THICK, k);
-    double perm;
-    if (CFG(snow_flush_flag) == 1) {
-      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k) + 2.0 * LAY(SAMSIM_A_PSI_G, k)));
-      if (perm == 0.0) perm = 1.0;
-    } else {
-      perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)));
+  for (int k0 = Na; k0 >= 1; k0 -= RARE_CHUNK) {
+    double th_[RARE_CHUNK], pl_[RARE_CHUNK], pg_[RARE_CHUNK];
+#pragma unroll
+    for (int i = 0; i < RARE_CHUNK; ++i) {
+      const int kk = (k0 - i >= 1) ? k0 - i : 1;
+      th_[i] = LAY(SAMSIM_A_THICK, kk); pl_[i] = LAY(SAMSIM_A_PSI_L, kk);
+      pg_[i] = (CFG(snow_flush_flag) == 1) ? LAY(SAMSIM_A_PSI_G, kk) : 0.0;
     }
-    LAY(SAMSIM_A_PERM, k) = perm;
-    const double pm = dmax(perm, 0.00000000000000000000001);
-    const double R_v = mu * thick / pm, R_h = mu * cnst / (thick * pm);
-    double R;
-    if (k == Na) R = 0.0;
-    else if (k == Na - 1) R = R_v;
-    else { R = R_below + R_v; R = ((R)*R_h) / (R + R_h); }
-    LAY(D_V_EX, k) = R;
-    R_below = R;
+#pragma unroll
+    for (int i = 0; i < RARE_CHUNK; ++i) {
+      const int k = k0 - i;
+      if (k >= 1) {
+        const double thick = th_[i];
+        double perm;
+        if (CFG(snow_flush_flag) == 1) {
+          perm = x.p17 * pow_3p1(1000.0 * fabs(pl_[i] + 2.0 * pg_[i]));
+          if (perm == 0.0) perm = 1.0;
+        } else {
+          perm = x.p17 * pow_3p1(1000.0 * fabs(pl_[i]));
+        }
+        LAY(SAMSIM_A_PERM, k) = perm;
+        const double pm = dmax(perm, 0.00000000000000000000001);
+        const double R_v = mu * thick / pm, R_h = mu * cnst / (thick * pm);
+        double R;
+        if (k == Na) R = 0.0;
+        else if (k == Na - 1) R = R_v;
+        else { R = R_below + R_v; R = ((R)*R_h) / (R + R_h); }
+        LAY(D_V_EX, k) = R;
+        R_below = R;
+      }
+    }
   }
   const double R1 = R_below;
   double flush_total = (GS(FREEBOARD) + CL(melt_thick)) / R1 * grav_f * dt * func_density(T1, S_br_poly(s, T1)) * rho_l;
@@ -2007,15 +2111,28 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   double T_up = 0.0, S_bu_up = 0.0, S_abs_up = 0.0;    // layer k-1: T, local S_bu snapshot, S_abs after the vertical transfer
   double sum_fh = 0.0, accH = 0.0, accS = 0.0, minS = 1.0e300;
   double S_bu_N = 0.0;
-  for (int k = 1; k <= Na; ++k) {
-    const double thick = LAY(SAMSIM_A_THICK, k), perm = LAY(SAMSIM_A_PERM, k), T = LAY(SAMSIM_A_T, k);
-    double m = LAY(SAMSIM_A_M, k), S_abs = LAY(SAMSIM_A_S_ABS, k), H_abs = LAY(SAMSIM_A_H_ABS, k);
+  constexpr int CH2 = RARE_CHUNK / 2;   // nine operands per layer
+  for (int k0 = 1; k0 <= Na; k0 += CH2) {
+    double th_[CH2], pe_[CH2], T_[CH2], m_[CH2], S_[CH2], H_[CH2], Rn_[CH2], fvv_[CH2], fhh_[CH2];
+#pragma unroll
+    for (int i = 0; i < CH2; ++i) {
+      const int kk = (k0 + i <= N) ? k0 + i : N, kn = (kk + 1 <= N) ? kk + 1 : N;
+      th_[i] = LAY(SAMSIM_A_THICK, kk); pe_[i] = LAY(SAMSIM_A_PERM, kk); T_[i] = LAY(SAMSIM_A_T, kk);
+      m_[i] = LAY(SAMSIM_A_M, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk); H_[i] = LAY(SAMSIM_A_H_ABS, kk);
+      Rn_[i] = LAY(D_V_EX, kn); fvv_[i] = LAY(SAMSIM_A_FLUSH_V, kk); fhh_[i] = LAY(SAMSIM_A_FLUSH_H, kk);
+    }
+#pragma unroll
+    for (int i = 0; i < CH2; ++i) {
+    const int k = k0 + i;
+    if (k <= Na) {
+    const double thick = th_[i], perm = pe_[i], T = T_[i];
+    double m = m_[i], S_abs = S_[i], H_abs = H_[i];
     const double S_bu = S_abs / m;  // local S_bu of flush3 (mo_flush.f90:101)
     const double pm = dmax(perm, 0.00000000000000000000001);
     const double R_v = mu * thick / pm, R_h = mu * cnst / (thick * pm);
     double fh, fv;
     if (k <= Na - 1) {
-      const double Rn = LAY(D_V_EX, k + 1);
+      const double Rn = Rn_[i];
       const double src = (k == 1) ? flush_total : fv_up;
       fh = src * (Rn + R_v) / (Rn + R_v + R_h);
       fv = src * R_h / (Rn + R_v + R_h);
@@ -2023,8 +2140,8 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
       fv = fv_up;
       fh = 0.0;
     }
-    LAY(SAMSIM_A_FLUSH_V, k) = LAY(SAMSIM_A_FLUSH_V, k) + fv;  // accumulated output, mo_grotz.f90:697-737
-    LAY(SAMSIM_A_FLUSH_H, k) = LAY(SAMSIM_A_FLUSH_H, k) + fh;
+    LAY(SAMSIM_A_FLUSH_V, k) = fvv_[i] + fv;  // accumulated output, mo_grotz.f90:697-737
+    LAY(SAMSIM_A_FLUSH_H, k) = fhh_[i] + fh;
     if (HAS_BGC) { BFL(BFL_V, k) = fv; BFL(BFL_H, k) = fh; }
     sum_fh += fh;
     const double flm_next = -fv, flm_k = -fv_up;
@@ -2063,6 +2180,8 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_S_ABS, k) = S_abs;
     LAY(SAMSIM_A_H_ABS, k) = H_abs;
     minS = dmin(minS, S_abs);
+    }
+    }
   }
   if (minS < -0.00000000000000000000000001) {
     for (int k = 1; k <= Na; ++k) {
@@ -2408,10 +2527,10 @@ __device__ RARE void output_point(Col &c, const Ctx &x, long long col, double ti
     OUT(SAMSIM_S_ENERGY_STORED, c.energy_stored); OUT(SAMSIM_S_FRESHWATER, c.freshwater); OUT(SAMSIM_S_TOTAL_RESIST, c.total_resist);
     OUT(SAMSIM_S_THICKNESS, c.thickness); OUT(SAMSIM_S_BULK_SALIN, c.bulk_salin);
     OUT(SAMSIM_S_FL_REST, (CFG(boundflux_flag) == 2 && (!K::general || CFG(atmoflux_flag) == 2)) ? CL(fl_lw) + 0.0 + 0.0
-                                                                        : x.scal[(size_t)SAMSIM_S_FL_REST * c.ncol + c.col]);
+                                                                        : GSI(SAMSIM_S_FL_REST));
     OUT(SAMSIM_S_S_BU_BOTTOM, x.S_bu_bottom);
-    OUT(SAMSIM_S_DT2M, x.scal[(size_t)SAMSIM_S_DT2M * c.ncol + c.col]);
-    OUT(SAMSIM_S_PRECIP_SCALE, x.scal[(size_t)SAMSIM_S_PRECIP_SCALE * c.ncol + c.col]);
+    OUT(SAMSIM_S_DT2M, GSI(SAMSIM_S_DT2M));
+    OUT(SAMSIM_S_PRECIP_SCALE, GSI(SAMSIM_S_PRECIP_SCALE));
 #undef OUT
     x.out_n_active[oc] = c.Na;
     if (HAS_BGC) {
@@ -2625,8 +2744,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
       CL(liquid_precip) = (1.0 - temp) * x.f_precip[x.soff + tc - 2] + temp * x.f_precip[x.soff + tc - 1];
     }
     // the column's perturbation (samsim_set_forcing): two words of the scalar block, read where they are used
-    CL(T2m) = CL(T2m) + x.scal[(size_t)SAMSIM_S_DT2M * c.ncol + c.col];
-    CL(liquid_precip) = CL(liquid_precip) * x.scal[(size_t)SAMSIM_S_PRECIP_SCALE * c.ncol + c.col];
+    CL(T2m) = CL(T2m) + GSI(SAMSIM_S_DT2M);
+    CL(liquid_precip) = CL(liquid_precip) * GSI(SAMSIM_S_PRECIP_SCALE);
   }
 
   c.bgc_flood = 0.0; c.bgc_grav = false;
@@ -2637,7 +2756,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // first thermodynamic sweep, mo_grotz.f90:297-307 (+ Rayleigh numbers): only layer 1 is left to do unless the
   // column changed below layer 1 since the last up sweep
   c.ray_all = (c.flags & COLF_DIRTY) != 0;
-  if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); sweep_thermo_expulsion<K>(c, x); }
+  if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); ST_COUNT(CT_L_DIRTY, (unsigned long long)__popcll(__ballot(1))); sweep_thermo_expulsion<K>(c, x); }
   else prologue_top_layer<K>(c, x);
   c.flags &= COLF_REGULAR;
   if (c.status) return;
@@ -2650,17 +2769,33 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool coupling = (CL(m_snow) > 0.0 && CL(thick_snow) < g.thick_min);
   const bool flood_possible = (CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                CL(m_snow) > c.buoy_s * (rho_l - rho_s));
-  const bool fused = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
+  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2)
 #if SAMSIM_THICK_RULE
                      && (c.flags & COLF_REGULAR) != 0   // the fused down sweep takes the thicknesses from the grid rule only
 #endif
       ;
+  // SAMSIM_PATH_MODE 2 (default): one path per wave.  A wave whose columns disagree runs both paths one after the other, each
+  // with part of its lanes idle -- the normal state of a melt season, when some column of almost every wave has thin snow or a
+  // flooded surface.  The unfused path is the general one (the reference's order, literally) and gives a column the same bits as
+  // the fused one (tools/path_equiv.py compares the two on the GPU), so a wave in which any column needs it takes it for all.
+  // 0 = per column, 1 = always unfused (the checker's reference for path_equiv).
+#if SAMSIM_PATH_MODE == 1
+  const bool fused = false;
+#elif SAMSIM_PATH_MODE == 2
+  const bool fused = (__ballot(!fused_col) == 0ull);
+#else
+  const bool fused = fused_col;
+#endif
 
   ST_MARK(ST_PRO);
   ST_COUNT(CT_WAVESTEPS, 1);
   ST_COUNT(CT_LANES, (unsigned long long)__popcll(__ballot(1)));
+  ST_COUNT(CT_L_COUPLING, (unsigned long long)__popcll(__ballot(coupling)));
+  ST_COUNT(CT_L_FLOODP, (unsigned long long)__popcll(__ballot(flood_possible)));
+  ST_COUNT(CT_L_IRREG, (unsigned long long)__popcll(__ballot((c.flags & COLF_REGULAR) == 0)));
+  ST_COUNT(CT_L_UNFUSED, (unsigned long long)__popcll(__ballot(!fused_col)));
   bool surface_done = false;   // the fused down sweep has evaluated the surface balance already
   if (fused) {
     ST_COUNT(CT_FUSED, 1);
@@ -2731,6 +2866,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || T_surf >= T_freeze) {
       if (!c.psi_full) STOPC(9001, 0);
+      ST_COUNT(CT_L_FREEBOARD, (unsigned long long)__popcll(__ballot(1)));
       GS(FREEBOARD) = func_freeboard<K>(c, x);
       fb_valid = true;
       if (GS(FREEBOARD) > 0.0000000000001) {
@@ -2805,6 +2941,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
         }
       } else {
         if (CL(melt_thick_snow) > 0.0) GS(FREEBOARD) = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
+        ST_COUNT(CT_L_FLUSH3, (unsigned long long)__popcll(__ballot(1)));
         flush3<K>(c, x);
         c.flags |= COLF_DIRTY;
         if (c.status) return;
@@ -2820,6 +2957,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     const double th1 = LAY(SAMSIM_A_THICK, 1);
     if (LAY(SAMSIM_A_PHI, Na) > psi_s_min || LAY(SAMSIM_A_PHI, Na - 1) <= psi_s_min / 2.0 || th1 / g.thick_0 > 1.5 ||
         th1 / g.thick_0 < 0.5) {
+      ST_COUNT(CT_L_REGRID, (unsigned long long)__popcll(__ballot(1)));
       layer_dynamics<K>(c, x);
       c.flags |= COLF_DIRTY;
       if (c.status) return;
@@ -2962,6 +3100,17 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
       long long col_step = col;
 #if SAMSIM_LAUNDER_COL
       asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(col_step));
+#endif
+#if SAMSIM_LAUNDER_COL >= 2
+      // the same for the wave-uniform strides: row and array bases are formed on the scalar unit where a sweep starts, instead of
+      // being kept (and moved in and out of spill lanes) for the whole launch
+      {
+        unsigned rs = __builtin_amdgcn_readfirstlane(c.rstride);
+        unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)c.astride), ahi = __builtin_amdgcn_readfirstlane((unsigned)(c.astride >> 32));
+        asm volatile("" : "+s"(rs), "+s"(alo), "+s"(ahi));
+        c.rstride = rs;
+        c.astride = ((size_t)ahi << 32) | (size_t)alo;
+      }
 #endif
       column_step<K>(c, x, col_step, time, tc, out_step, next_out, s + 1 == p.nsteps);
     }

@@ -18,7 +18,8 @@ import bench  # noqa: E402
 
 NAMES = ["t_prologue", "t_down_fused", "t_down_unfused", "t_surface", "t_up", "t_post", "t_head", "t_tail",
          "wave_steps", "fused", "unfused", "up_trips", "newton_wave", "newton_lane", "lanes", "down_trips", "drain_wave",
-         "drain_lane", "dirty", "_19", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC"]
+         "drain_lane", "dirty", "lanes_coupling", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC",
+         "lanes_flood_possible", "lanes_irregular", "lanes_dirty", "lanes_unfused", "lanes_flush3", "lanes_regrid", "lanes_freeboard"]
 
 
 def main():
