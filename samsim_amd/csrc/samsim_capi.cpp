@@ -162,9 +162,27 @@ __global__ void refresh_s_bu(double *lay, const int32_t *n_active, const int32_t
   if (status[c]) return;   // a column that stopped keeps what it held (its masses may be zero)
   const int na = n_active[c];
   for (int k = 0; k < na; ++k) {
-    const double m = lay[((size_t)SAMSIM_A_M * N + k) * ncol + c];
-    if (m != 0.0) lay[((size_t)SAMSIM_A_S_BU * N + k) * ncol + c] = lay[((size_t)SAMSIM_A_S_ABS * N + k) * ncol + c] / m;
+    const double m = lay[DEV_LAY_INDEX(SAMSIM_A_M, k, c, N, ncol)];
+    if (m != 0.0) lay[DEV_LAY_INDEX(SAMSIM_A_S_BU, k, c, N, ncol)] = lay[DEV_LAY_INDEX(SAMSIM_A_S_ABS, k, c, N, ncol)] / m;
   }
+}
+
+// The boundary keeps [array][layer][column] (samsim_state_soa); the device layout is DEV_LAY_INDEX.  A window of columns passes
+// through a staging buffer in the boundary's layout: scatter = staging -> device layout, gather = the reverse.
+template <bool GATHER>
+__global__ void lay_window(double *lay, double *stage, int narr, int N, size_t ncol, size_t col0, size_t w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)narr * N * w) return;
+  const size_t cw = i % w, ak = i / w;
+  const int k = (int)(ak % (size_t)N), a = (int)(ak / (size_t)N);
+  const size_t j = DEV_LAY_INDEX(a, k, col0 + cw, N, ncol);
+  if (GATHER) stage[i] = lay[j]; else lay[j] = stage[i];
+}
+// one value into every layer of one array
+__global__ void lay_fill_array(double *lay, int a, int N, size_t ncol, double v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * ncol) return;
+  lay[DEV_LAY_INDEX(a, (int)(i / ncol), i % ncol, N, ncol)] = v;
 }
 
 hipError_t fill(double *dst, size_t n, double v, hipStream_t s) {
@@ -279,7 +297,7 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   h->tf_c3 = (double)(5.33f * std::pow(10.0f, -7.0f));
   const size_t N = (size_t)cfg->nlayer, nc = (size_t)ncol;
   bool ok = hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
-  ok = ok && hip_ok(dalloc(&h->lay, (size_t)DEV_NARR * N * nc), "hipMalloc lay");
+  ok = ok && hip_ok(dalloc(&h->lay, DEV_LAY_DOUBLES(N, nc)), "hipMalloc lay");
   ok = ok && hip_ok(dalloc(&h->scal, (size_t)SAMSIM_NSCAL * nc), "hipMalloc scal");
   ok = ok && hip_ok(dalloc(&h->n_active, nc), "hipMalloc n_active");
   ok = ok && hip_ok(dalloc(&h->status, nc), "hipMalloc status");
@@ -294,16 +312,20 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   ok = ok && hip_ok(hipEventCreate(&h->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&h->ev1), "hipEventCreate");
   if (ok) {
     // sub_allocate zeros (mo_init.f90:2081-2087) and the defaults of mo_init.f90:1982-1990
-    ok = hip_ok(hipMemsetAsync(h->lay, 0, sizeof(double) * DEV_NARR * N * nc, h->stream), "memset lay");
+    ok = hip_ok(hipMemsetAsync(h->lay, 0, sizeof(double) * DEV_LAY_DOUBLES(N, nc), h->stream), "memset lay");
     ok = ok && hip_ok(hipMemsetAsync(h->scal, 0, sizeof(double) * SAMSIM_NSCAL * nc, h->stream), "memset scal");
     ok = ok && hip_ok(hipMemsetAsync(h->status, 0, sizeof(int32_t) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->err_layer, 0, sizeof(int32_t) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->err_step, 0, sizeof(long long) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->work, 0, sizeof(long long) * nc, h->stream), "memset");
     ok = ok && hip_ok(hipMemsetAsync(h->spec, 0, sizeof(double) * DEV_NSPEC * nc, h->stream), "memset");
-    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_T * N * nc, N * nc, cfg->T_bottom, h->stream), "fill T");
-    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_S_BU * N * nc, N * nc, cfg->S_bu_bottom, h->stream), "fill S_bu");
-    ok = ok && hip_ok(fill(h->lay + (size_t)SAMSIM_A_PSI_L * N * nc, N * nc, 1.0, h->stream), "fill psi_l");
+    if (ok) {
+      const unsigned fg = (unsigned)((N * nc + 255) / 256);
+      hipLaunchKernelGGL(lay_fill_array, dim3(fg), dim3(256), 0, h->stream, h->lay, (int)SAMSIM_A_T, (int)N, nc, cfg->T_bottom);
+      hipLaunchKernelGGL(lay_fill_array, dim3(fg), dim3(256), 0, h->stream, h->lay, (int)SAMSIM_A_S_BU, (int)N, nc, cfg->S_bu_bottom);
+      hipLaunchKernelGGL(lay_fill_array, dim3(fg), dim3(256), 0, h->stream, h->lay, (int)SAMSIM_A_PSI_L, (int)N, nc, 1.0);
+      ok = hip_ok(hipGetLastError(), "fill layer arrays");
+    }
     ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_PRECIP_SCALE * nc, nc, 1.0, h->stream), "fill precip_scale");
     ok = ok && hip_ok(fill(h->scal + (size_t)SAMSIM_S_S_BU_BOTTOM * nc, nc, cfg->S_bu_bottom, h->stream), "fill S_bu_bottom");
     if (ok) {
@@ -419,8 +441,20 @@ int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0) 
   const size_t N = (size_t)s->nlayer, nc = (size_t)h->ncol, w = (size_t)s->ncol;
   for (size_t i = 0; i < w; ++i) if (s->n_active[i] < 1 || s->n_active[i] > (int)N) return SAMSIM_ERR_ARG;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy2D(h->lay + col0, nc * sizeof(double), s->lay, w * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
-                     hipMemcpyHostToDevice));
+  {
+    const size_t n = (size_t)s->narr * N * w;
+    double *stage = nullptr;
+    HIPCHK(dalloc(&stage, n));
+    hipError_t e = hipMemcpy(stage, s->lay, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(lay_window<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, stage, (int)s->narr, (int)N, nc,
+                         (size_t)col0, w);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(stage);
+    HIPCHK(e);
+  }
   // the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing: set_state leaves them alone
   HIPCHK(hipMemcpy2D(h->scal + col0, nc * sizeof(double), s->scal, w * sizeof(double), w * sizeof(double), (size_t)SAMSIM_S_DT2M,
                      hipMemcpyHostToDevice));
@@ -446,8 +480,18 @@ int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy2D(s->lay, w * sizeof(double), h->lay + col0, nc * sizeof(double), w * sizeof(double), (size_t)s->narr * N,
-                     hipMemcpyDeviceToHost));
+  {
+    const size_t n = (size_t)s->narr * N * w;
+    double *stage = nullptr;
+    HIPCHK(dalloc(&stage, n));
+    hipLaunchKernelGGL(lay_window<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, stage, (int)s->narr, (int)N, nc,
+                       (size_t)col0, w);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(s->lay, stage, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(stage);
+    HIPCHK(e);
+  }
   HIPCHK(hipMemcpy2D(s->scal, w * sizeof(double), h->scal + col0, nc * sizeof(double), w * sizeof(double), (size_t)SAMSIM_NSCAL,
                      hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(s->n_active, h->n_active + col0, w * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -116,13 +116,13 @@ constexpr double Turb_B = 0.05;
   X(boundflux_flag) X(flush_flag) X(flood_flag) X(bottom_flag) X(precip_flag) X(harmonic_flag) X(tank_flag) X(albedo_flag) \
   X(lab_snow_flag) X(freeboard_snow_flag) X(snow_flush_flag) X(snow_precip_flag) X(testcase)
 struct KGeneric {
-  static constexpr bool fixed = false, general = true, sites = true;
+  static constexpr bool fixed = false, general = true, sites = true, bgc = true;
 #define X(f) [[maybe_unused]] static constexpr int f = 0;
   SAMSIM_FLAG_LIST(X)
 #undef X
 };
 struct KSheba {  // init(4), mo_init.f90:1127-1207 on the defaults of :83-109
-  static constexpr bool fixed = true, general = false, sites = false;
+  static constexpr bool fixed = true, general = false, sites = false, bgc = false;
   static constexpr int atmoflux_flag = 2, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 2, turb_flag = 2,
                        salt_flag = 1, boundflux_flag = 2, flush_flag = 5, flood_flag = 2, bottom_flag = 1, precip_flag = 1,
                        harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
@@ -132,11 +132,18 @@ struct KShebaSites : KSheba {  // the same on several forcing sets (samsim_set_f
   static constexpr bool sites = true;
 };
 struct KPlate {  // init(1), mo_init.f90:865-945 (bgc off)
-  static constexpr bool fixed = true, general = false, sites = false;
+  static constexpr bool fixed = true, general = false, sites = false, bgc = false;
   static constexpr int atmoflux_flag = 1, grav_flag = 2, prescribe_flag = 1, grav_heat_flag = 1, flush_heat_flag = 1, turb_flag = 1,
                        salt_flag = 2, boundflux_flag = 1, flush_flag = 1, flood_flag = 2, bottom_flag = 1, precip_flag = 0,
                        harmonic_flag = 2, tank_flag = 1, albedo_flag = 2, lab_snow_flag = 0, freeboard_snow_flag = 0,
                        snow_flush_flag = 1, snow_precip_flag = 1, testcase = 1;
+};
+// the same flag sets carrying passive tracers (bgc_flag 2: testcase 1 as init ships it; a SHEBA ensemble with tracers)
+struct KPlateBgc : KPlate {
+  static constexpr bool bgc = true;
+};
+struct KShebaBgc : KSheba {
+  static constexpr bool bgc = true;
 };
 template <class K>
 bool flags_match(const samsim_config &g) {
@@ -194,7 +201,8 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 struct Col {
   gdouble *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
   unsigned col; // this lane's column
-  unsigned coff;     // col * 8: byte offset of the column inside a row
+  unsigned coff;     // col * 8: byte offset of the column inside a row of the scalar / hand-over blocks
+  unsigned lcoff;    // lane * 8: byte offset of the column inside a row of its 64-column block (SAMSIM_BLOCKED)
   unsigned rstride;  // UNIFORM ncol * 8: bytes per row
   size_t astride;    // UNIFORM nlayer * ncol * 8: bytes per layer array
   size_t ncol;
@@ -267,7 +275,7 @@ struct Col {
 #define RARE_CHUNK 8
 #endif
 #ifndef SAMSIM_PATH_MODE
-#define SAMSIM_PATH_MODE 0
+#define SAMSIM_PATH_MODE 2
 #endif
 // SAMSIM_LAUNDER_COL: the column index is re-declared to the optimiser at every time step (see samsim_step_kernel)
 #ifndef SAMSIM_LAUNDER_COL
@@ -281,8 +289,18 @@ struct Col {
 // hardware loads with a scalar base and ONE 32-bit offset register per row (global_load ... v_off, s[base:base+1]); all arrays
 // of a row share the offset register.  (A 64-bit per-lane address for every array costs two registers each and 64-bit vector
 // arithmetic per access.)  Needs nlayer * ncol * 8 < 4 GiB per handle; samsim_create checks it.
+#if SAMSIM_BLOCKED
+// Blocked layout (samsim_device.h): c.lay points 4096 bytes into the wave's own column block, so that array a of layer row k is at
+// c.lay + (k-1)*DEV_ROWB + (a*512 - 4096) + lane*8: sixteen arrays within the signed 13-bit immediate of one row address.
+// LAY takes any k (one 32-bit offset register per row, the lane's part included); LAYU is for a wave-uniform k: the row address is
+// scalar arithmetic and the vector offset is the lane's constant c.lcoff.
+#define LAY(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(unsigned)(((unsigned)(k) - 1u) * (unsigned)DEV_ROWB + c.lcoff) + (ptrdiff_t)((int)(a) * 512 - 4096)))
+#define LAYU(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(((unsigned)(k) - 1u) * (unsigned)DEV_ROWB) + (size_t)c.lcoff + (ptrdiff_t)((int)(a) * 512 - 4096)))
+#else
 #define ROWOFF(k) ((unsigned)(((unsigned)((k) - 1)) * c.rstride + c.coff))
 #define LAY(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(a) * c.astride + (size_t)ROWOFF(k)))
+#define LAYU(a, k) LAY(a, k)
+#endif
 #define SPEC(i) (*(gdouble *)((gchar *)c.spec + (size_t)(unsigned)((unsigned)(i) * c.rstride + c.coff)))
 #endif
 #define STOPC(code, layer)            \
@@ -590,7 +608,7 @@ struct Ctx {
 #define BGC_BOT(t) (x.bgc_bot + (size_t)(t) * c.ncol)[c.col]
 #define BFL(r, k) (x.bfl + ((size_t)(r) * (size_t)c.N + (size_t)((k) - 1)) * c.ncol)[c.col]
 // tracers exist only in the run-time-flag instantiation; in the fixed ones the test folds to false
-#define HAS_BGC (K::general && x.n_bgc > 0)
+#define HAS_BGC (K::bgc && x.n_bgc > 0)
 
 // density of the water below the ice (sub_turb_flux, mo_functions.f90:355): the same number in every step of every column unless
 // the tank budget (tank_flag 2) moves S_bu_bottom
@@ -942,9 +960,9 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
 #endif
       ray = dmax(ray, 0.0);
       if (!sparse_rows) {
-        LAY(SAMSIM_A_RAY, k) = ray;
+        LAYU(SAMSIM_A_RAY, k) = ray;
       } else if (x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // the fused up sweep: wave-uniform k, see Ctx::rflag
-        LAY(SAMSIM_A_RAY, k) = ray;
+        LAYU(SAMSIM_A_RAY, k) = ray;
         if (wave_leader()) x.rflag[(k - 1) >> 6] |= 1ull << ((k - 1) & 63);
       }
     }
@@ -961,17 +979,17 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   RayScan r;
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
-  if (do_ray && Na <= c.N - 1) LAY(SAMSIM_A_RAY, Na) = 0.0;
+  if (do_ray && Na <= c.N - 1) LAYU(SAMSIM_A_RAY, Na) = 0.0;
   // operands requested two layers ahead of the arithmetic, unconditionally and from a clamped row, as in sweep_up_fused
   struct L4 { double H, m, th, S; };
   auto ld = [&](int j) -> L4 {
     L4 r;
-    r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.th = LAY(SAMSIM_A_THICK, j); r.S = LAY(SAMSIM_A_S_ABS, j);
+    r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.th = LAYU(SAMSIM_A_THICK, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
     return r;
   };
   L4 cur = ld(Na), nxt = ld(Na >= 2 ? Na - 1 : 1), nn = nxt;
   bool regular = true;
-  const double th_mid_rule = LAY(SAMSIM_A_THICK, g.n_top + 1);
+  const double th_mid_rule = LAYU(SAMSIM_A_THICK, g.n_top + 1);
   const int kmax = wave_max(Na);
   for (int k = kmax; k >= 1; --k) {
     if (k > Na) continue;
@@ -982,7 +1000,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     cur = nxt; nxt = nn;
     if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
       S_abs = 0.0;
-      LAY(SAMSIM_A_S_ABS, k) = S_abs;
+      LAYU(SAMSIM_A_S_ABS, k) = S_abs;
     }
     double S_bu, H;
     per_mass(S_abs, H_abs, m, S_bu, H);
@@ -991,8 +1009,8 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
     // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
-    LAY(SAMSIM_A_T, k) = T;
-    LAY(SAMSIM_A_PHI, k) = phi;
+    LAYU(SAMSIM_A_T, k) = T;
+    LAYU(SAMSIM_A_PHI, k) = phi;
     s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
   }
   c.neg_psi = r.min_psi_s < 0.0;
@@ -1399,13 +1417,13 @@ __device__ RARE void sweep_beer(Col &c, const Ctx &x, double beer0) {
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
 #if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
-  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+  const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
 #endif
   for (int k = 1; k <= Na; ++k) {
 #if SAMSIM_THICK_RULE
-    const double thick = (regular && k >= 2) ? thick_by_rule(k, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, k);
+    const double thick = (regular && k >= 2) ? thick_by_rule(k, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, k);
 #else
-    const double thick = LAY(SAMSIM_A_THICK, k);
+    const double thick = LAYU(SAMSIM_A_THICK, k);
 #endif
     if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
     if (k == Na) c.frad = temp2 - temp2 * e;
@@ -1506,26 +1524,26 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   struct Ld { double T, S_abs, m, H_abs, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
 #if SAMSIM_THICK_RULE
-  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+  const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
 #endif
   auto load_ld = [&](int j) -> Ld {
     Ld r;
-    r.T = LAY(SAMSIM_A_T, j);
-    r.S_abs = LAY(SAMSIM_A_S_ABS, j);
-    r.m = LAY(SAMSIM_A_M, j);
-    r.H_abs = LAY(SAMSIM_A_H_ABS, j);
+    r.T = LAYU(SAMSIM_A_T, j);
+    r.S_abs = LAYU(SAMSIM_A_S_ABS, j);
+    r.m = LAYU(SAMSIM_A_M, j);
+    r.H_abs = LAYU(SAMSIM_A_H_ABS, j);
     // (the row flags are read from LDS at every layer: a word kept across iterations is one more value the allocator spills,
     // and a scratch reload drains every outstanding request of the sweep)
-    r.ray = (j <= Na - 1 && ray_row_valid(c, x, j)) ? LAY(SAMSIM_A_RAY, j) : 0.0;
+    r.ray = (j <= Na - 1 && ray_row_valid(c, x, j)) ? LAYU(SAMSIM_A_RAY, j) : 0.0;
     return r;
   };
   auto finish = [&](const Ld &l, int j) -> Raw {
     Raw r;
     r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.ray = l.ray;
 #if SAMSIM_THICK_RULE
-    r.thick = (j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
+    r.thick = (j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
 #else
-    r.thick = LAY(SAMSIM_A_THICK, j);
+    r.thick = LAYU(SAMSIM_A_THICK, j);
 #endif
     per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
@@ -1573,9 +1591,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     // The up sweep only needs the layer's half resistance thick/(2k) (sub_fl_Q, mo_thermo_functions.f90:201-223); the three
     // volume fractions are stored when something reads them this step (see column_step), and always for layer 1
     if (store_psi || j == 1) {
-      LAY(SAMSIM_A_PSI_S, j) = ex.psi_s;
-      LAY(SAMSIM_A_PSI_L, j) = ex.psi_l;
-      LAY(SAMSIM_A_PSI_G, j) = psi_g;
+      LAYU(SAMSIM_A_PSI_S, j) = ex.psi_s;
+      LAYU(SAMSIM_A_PSI_L, j) = ex.psi_l;
+      LAYU(SAMSIM_A_PSI_G, j) = psi_g;
     }
     // sub_fl_Q (mo_thermo_functions.f90:201-223): fl_Q(j) = (T(j) - T(j-1)) / (thick(j-1)/(2k(j-1)) + thick(j)/(2k(j))) with the
     // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op)
@@ -1653,9 +1671,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
         prev.H_abs = prev.H_abs + c.frad * dt;
         esum += H_b - prev.H_abs;
       }
-      LAY(SAMSIM_A_M, j - 1) = prev.m;
-      LAY(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
-      LAY(SAMSIM_A_H_ABS, j - 1) = prev.H_abs;
+      LAYU(SAMSIM_A_M, j - 1) = prev.m;
+      LAYU(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
+      LAYU(SAMSIM_A_H_ABS, j - 1) = prev.H_abs;
       minS = dmin(minS, prev.S_abs);
       flup_pp = prev.flup;
     }
@@ -1682,7 +1700,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     surface_flux<K>(c, x);
     surface_done = true;
     const double thick_min = g.thick_min;
-    const double Tf = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
+    const double Tf = func_T_freeze(LAYU(SAMSIM_A_S_ABS, 1) / LAYU(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
     bool snow_wet = false;
     if (CL(thick_snow) > 0.0) {
       // snow_thermo finds liquid water iff H_abs_snow / m_snow > -latent_heat (getT's fresh branch); the up sweep adds
@@ -1690,7 +1708,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       const double H_new = CL(H_abs_snow) + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
       snow_wet = !(CL(thick_snow) >= thick_min) || !(H_new / CL(m_snow) <= -latent_heat);
     }
-    store_psi = store_default || LAY(SAMSIM_A_PSI_S, 1) < psi_s_top_min || CL(T_top) >= Tf || snow_wet || CL(melt_thick_snow) > 0.0;
+    store_psi = store_default || LAYU(SAMSIM_A_PSI_S, 1) < psi_s_top_min || CL(T_top) >= Tf || snow_wet || CL(melt_thick_snow) > 0.0;
   } else {
     store_psi = store_default || decide_psi;   // (a deciding sweep over fewer than three layers has nothing left to skip)
   }
@@ -1760,9 +1778,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     prev.H_abs = prev.H_abs + c.frad * dt;
     c.esum = esum + (H_b - prev.H_abs);
   }
-  LAY(SAMSIM_A_M, Na) = prev.m;
-  LAY(SAMSIM_A_S_ABS, Na) = prev.S_abs;
-  LAY(SAMSIM_A_H_ABS, Na) = prev.H_abs;
+  LAYU(SAMSIM_A_M, Na) = prev.m;
+  LAYU(SAMSIM_A_S_ABS, Na) = prev.S_abs;
+  LAYU(SAMSIM_A_H_ABS, Na) = prev.H_abs;
   minS = dmin(minS, prev.S_abs);
   c.buoy_g = buoy_g;
   CL(grav_salt) = CL(grav_salt) + sum_before;
@@ -1908,10 +1926,10 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   ray_scan_init(r);
   if (keep_ray) {  // `output` prints the Rayleigh numbers of THIS step's fl_grav_drain at the next step's output point
     const size_t oc = (size_t)(col - x.out_col0), on = (size_t)x.out_ncols;
-    for (int k = 1; k <= c.N - 1; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * c.N + (k - 1)) * on + oc] = LAY(SAMSIM_A_RAY, k);
+    for (int k = 1; k <= c.N - 1; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * c.N + (k - 1)) * on + oc] = LAYU(SAMSIM_A_RAY, k);
   }
   for (int w = 0; w <= (c.N - 1) >> 6; ++w) x.rflag[w] = 0ull;   // every lane writes the same zeros
-  if (do_ray && Na <= c.N - 1 && x.ray_rows_all) LAY(SAMSIM_A_RAY, Na) = 0.0;   // (read by `output` only)
+  if (do_ray && Na <= c.N - 1 && x.ray_rows_all) LAYU(SAMSIM_A_RAY, Na) = 0.0;   // (read by `output` only)
   // The conductive update of layers >= 2 has been applied by the down sweep (sweep_down_fused / sweep_heat_down), which also
   // hands over fl_Q(2) and the energy sums: this sweep reads the finished enthalpy and runs the second getT chain -- and, for
   // layers N_active..2, the first sweep of the next step.  Its operands (H_abs, m, S_abs, thick of a layer) are requested TWO
@@ -1921,16 +1939,16 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   struct UL { double th, H, m, S; };
 #if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
-  const double th_mid = LAY(SAMSIM_A_THICK, g.n_top + 1);
+  const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
 #endif
   auto load_ul = [&](int j) -> UL {
     UL r;
 #if SAMSIM_THICK_RULE
-    r.th = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAY(SAMSIM_A_THICK, j);
+    r.th = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, j);
 #else
-    r.th = LAY(SAMSIM_A_THICK, j);
+    r.th = LAYU(SAMSIM_A_THICK, j);
 #endif
-    r.H = LAY(SAMSIM_A_H_ABS, j); r.m = LAY(SAMSIM_A_M, j); r.S = LAY(SAMSIM_A_S_ABS, j);
+    r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
     return r;
   };
   UL cur = load_ul(Na), nxt = load_ul(Na >= 2 ? Na - 1 : 1), nn = nxt;   // layers k, k-1, k-2
@@ -1952,15 +1970,15 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
       // snow treatment, mo_heat_fluxes.f90:291-303
       if (thin_snow) {
         CL(H_abs_snow) = CL(H_abs_snow) - CL(fl_Q_snow) * dt;
-        LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+        LAYU(SAMSIM_A_H_ABS, 1) = H_abs;
         snow_coupling<K>(c, x);
         if (c.status) { alive = false; return; }
-        H_abs = LAY(SAMSIM_A_H_ABS, 1);
+        H_abs = LAYU(SAMSIM_A_H_ABS, 1);
       } else if (CL(thick_snow) >= thick_min) {
         CL(H_abs_snow) = CL(H_abs_snow) + (CL(fl_Q1) - CL(fl_Q_snow)) * dt;
       }
       esum += H_b - H_abs;   // (after the thin-snow coupling, which moves enthalpy between the snow and layer 1)
-      LAY(SAMSIM_A_H_ABS, 1) = H_abs;
+      LAYU(SAMSIM_A_H_ABS, 1) = H_abs;
     }
     double S_abs = S_k;
     double S_bu, H;
@@ -1982,10 +2000,10 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     ST_MARK(ST_U_GETT);
     if (rr && !rc) { rc = rr; rc_layer = k; }
     T_test = T;
-    LAY(SAMSIM_A_T, k) = T;
+    LAYU(SAMSIM_A_T, k) = T;
     // the down sweeps recompute phi from T; the array is kept for its readers: the regrid trigger and layer_dynamics (bottom
     // two active layers), layer 1, the output snapshot and get_state
-    if (store_phi || TOP || k >= Na - 1) LAY(SAMSIM_A_PHI, k) = phi;
+    if (store_phi || TOP || k >= Na - 1) LAYU(SAMSIM_A_PHI, k) = phi;
     if (!TOP) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
       if (S_abs < 0.0) {
@@ -2256,12 +2274,12 @@ __device__ RARE void bgc_advection(Col &c, const Ctx &x) {
 // else written (m, H_abs, thick, N_active stay as they are, so every replay and then the proper pass see the old profile).
 template <class K>
 __device__ __forceinline__ gdouble &salt_at(Col &c, const Ctx &x, int tr, int k) {
-  if (K::general && tr >= 0) return BGC(tr, k);
+  if (K::bgc && tr >= 0) return BGC(tr, k);
   return LAY(SAMSIM_A_S_ABS, k);
 }
 template <class K>
 __device__ __forceinline__ double salt_below(Col &c, const Ctx &x, int tr) {
-  if (K::general && tr >= 0) return BGC_BOT(tr);
+  if (K::bgc && tr >= 0) return BGC_BOT(tr);
   return x.S_bu_bottom;
 }
 struct LayerVals { double rho, S_bu, H; };
@@ -3013,7 +3031,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.scal = (gdouble *)scal;
   x.bgc = (gdouble *)bgc; x.bgc_bot = (gdouble *)bgc_bot; x.bfl = (gdouble *)bfl;
   x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
-  x.n_bgc = K::general ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
+  x.n_bgc = K::bgc ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
   x.soff = (K::sites && p.nsites > 1) ? site[col] * p.flen : 0;
   x.dflq = (K::sites && p.ocean_dflq) ? p.ocean_dflq[col] : 0.0;
   x.ocean_sbu = K::sites && p.ocean_sbu != nullptr;
@@ -3033,9 +3051,14 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.st.t0 = __builtin_amdgcn_s_memtime();
 #endif
   Col c;
+#if SAMSIM_BLOCKED
+  c.lay = (gdouble *)((gchar *)lay + (size_t)blockIdx.x * ((size_t)p.cfg.nlayer * DEV_ROWB) + 4096);
+#else
   c.lay = (gdouble *)lay;
+#endif
   c.col = (unsigned)col;
   c.coff = (unsigned)col * 8u;
+  c.lcoff = threadIdx.x * 8u;
   c.rstride = (unsigned)p.ncol * 8u;
   c.astride = (size_t)p.cfg.nlayer * (size_t)p.ncol * 8u;
   c.ncol = (size_t)p.ncol;
@@ -3099,7 +3122,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
       // step: each is formed where it is used (two or three vector instructions) and nothing is carried.
       long long col_step = col;
 #if SAMSIM_LAUNDER_COL
-      asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(col_step));
+      asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(c.lcoff), "+v"(col_step));
 #endif
 #if SAMSIM_LAUNDER_COL >= 2
       // the same for the wave-uniform strides: row and array bases are formed on the scalar unit where a sweep starts, instead of
@@ -3152,11 +3175,12 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
   const int block = SAMSIM_BLOCK;
   const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
-  // tracers exist in the run-time-flag instantiation only; several forcing sets there and in the SHEBA one
+  // one instantiation per flag set; tracers (bgc_flag 2) and several forcing sets / oceans select their own
   const bool tracers = g.bgc_flag == 2, sites = hp->nsites > 1 || hp->ocean_dflq || hp->ocean_sbu;
-  auto kernel = (!tracers && !sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KSheba>
-                : (!tracers && sites && flags_match<KSheba>(g)) ? samsim_step_kernel<KShebaSites>
-                : (!tracers && !sites && flags_match<KPlate>(g)) ? samsim_step_kernel<KPlate> : samsim_step_kernel<KGeneric>;
+  auto kernel = samsim_step_kernel<KGeneric>;
+  if (!sites && flags_match<KSheba>(g)) kernel = tracers ? samsim_step_kernel<KShebaBgc> : samsim_step_kernel<KSheba>;
+  else if (!tracers && sites && flags_match<KSheba>(g)) kernel = samsim_step_kernel<KShebaSites>;
+  else if (!sites && flags_match<KPlate>(g)) kernel = tracers ? samsim_step_kernel<KPlateBgc> : samsim_step_kernel<KPlate>;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(block), 0, stream, d_params, hp->lay, hp->scal, hp->spec,
                      hp->n_active, hp->status, hp->err_layer, hp->err_step, hp->work, hp->flags, hp->f_sw, hp->f_lw, hp->f_T2m,
                      hp->f_precip, hp->out_lay, hp->out_scal, hp->out_n_active, hp->bgc, hp->bgc_bot, hp->bfl, hp->out_bgc,

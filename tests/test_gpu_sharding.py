@@ -94,3 +94,46 @@ def test_fortran_host_column_ranges(tmp_path):
         assert np.array_equal(na, whole[2][c0:c0 + 96])
     from samsim_amd.capi import S
     assert len(np.unique(whole[1][S["T2m"]])) > 96     # the perturbed air temperature differs from column to column
+
+
+def test_a_column_does_not_depend_on_its_wave_mates():
+    """The kernel takes some decisions per wave (one order of the step for all 64 columns when any of them has thin snow or a
+    flooded surface; Rayleigh-number rows stored where any
+    of them drains).  None of them may change a column's bits: the same 256 melt-season columns (day 345: snow-covered, thin
+    snow, bare, flushing) are run in their order and in a shuffled order -- other wave-mates, other decisions -- and every
+    column must come out identical."""
+    import bench
+    import samsim_amd
+    from samsim_amd import testcases as tcs
+    from samsim_amd.capi import State
+    z, st, clock, pert = bench.load_ensemble("sheba_ensemble_80_day345.npz")
+    cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
+    n = st.ncol
+    rng = np.random.default_rng(7)
+    results = []
+    for perm in (np.arange(n), rng.permutation(n)):
+        g = samsim_amd.hip_solver(cfg, n)
+        g.set_forcing(*bench.sheba_forcing(), np.ascontiguousarray(pert[0][perm]), np.ascontiguousarray(pert[1][perm]))
+        g.set_state(State(np.ascontiguousarray(st.lay[..., perm]), np.ascontiguousarray(st.scal[..., perm]),
+                          np.ascontiguousarray(st.n_active[perm]).astype(np.int32)))
+        g.set_clock(**clock)
+        g.set_output_window(0, 0)
+        g.step(1500)
+        s, status = g.get_state(), g.get_status()[0]
+        inv = np.argsort(perm)
+        results.append((s.lay[..., inv], s.scal[..., inv], s.n_active[inv], status[inv]))
+        g.close()
+    (la, sa, na, xa), (lb, sb, nb, xb) = results
+    assert not xa.any() and np.array_equal(xa, xb) and np.array_equal(na, nb)
+    assert np.array_equal(sa, sb)
+    act = np.arange(la.shape[1])[:, None] < na[None, :]
+    for i, name in enumerate(["H_abs", "S_abs", "m", "thick", "T", "phi", "psi_s", "psi_l", "psi_g", "S_bu"]):
+        assert np.array_equal(np.where(act, la[i], 0.0), np.where(act, lb[i], 0.0)), name
+    # the ensemble really is in the regime the decisions are about: part of it under thin snow, part of it bare
+    thin = (sa[bench_scalar_index("thick_snow")] > 0) & (sa[bench_scalar_index("thick_snow")] < float(cfg.thick_min))
+    assert 0 < thin.sum() < n or (sa[bench_scalar_index("thick_snow")] == 0).any()
+
+
+def bench_scalar_index(name):
+    from samsim_amd.capi import SCALARS
+    return list(SCALARS).index(name)
