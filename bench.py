@@ -214,7 +214,10 @@ def timed_window(g, substeps, launches, warmup, barrier):
     barrier()
     work_before, _ = g.get_work()
     t0 = time.perf_counter()
-    kernel_ms = [g.step_timed(substeps) for _ in range(launches)]
+    # the launches are enqueued back to back and timed as one region with HIP events on the handle's streams (a step of a large
+    # ensemble is two launches on two streams; no wait between steps, so the ragged end of one is filled by the next)
+    device_ms = g.steps_timed(substeps, launches)
+    kernel_ms = [device_ms / launches] * launches
     barrier()
     wall = time.perf_counter() - t0
     work_after, _ = g.get_work()
@@ -368,6 +371,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "samsim_step_kernel", "mean_launch_ms": mean_ms,
+                         "how": "HIP events around the K back-to-back steps on the launch streams, / K; a step of >= 8192 column "
+                                "blocks is two concurrent launches (5/8 and 3/8 of the columns on two streams)",
                          "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps,
                          "lib_md5": lib_md5()},
         }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAMSIM_ABI_VERSION 3
+#define SAMSIM_ABI_VERSION 4
 #define SAMSIM_MAX_NLAYER 1024
 
 /* -------- configuration: every flag of mo_data.f90:136-155 plus the scalars mo_init sets -------- */
@@ -176,6 +176,9 @@ int samsim_get_clock(samsim_handle *h, samsim_clock *c);
 int samsim_step(samsim_handle *h, int64_t nsteps);
 /* same, and returns the device time of the launch(es) measured with HIP events on the handle's stream */
 int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms);
+/* nlaunches launches of nsteps steps each, enqueued back to back (no wait in between: the tail of one launch is filled by the
+ * head of the next), and the device time of the whole sequence, measured with HIP events on the handle's streams (ABI 4) */
+int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, double *device_ms);
 int samsim_synchronize(samsim_handle *h);
 
 /* number of steps until (and including) the next output point of mo_grotz.f90:340 */

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _CFG_INT_FIELDS = [
     "struct_size", "testcase", "nlayer", "n_top", "n_middle", "n_bottom",
@@ -210,6 +210,8 @@ class Solver:
         vp, i64 = C.c_void_p, C.c_int64
         f = self._f("step_timed")
         f.argtypes, f.restype = [vp, i64, C.POINTER(C.c_double)], C.c_int
+        f = self._f("steps_timed")
+        f.argtypes, f.restype = [vp, i64, C.c_int32, C.POINTER(C.c_double)], C.c_int
         f = self._f("synchronize")
         f.argtypes, f.restype = [vp], C.c_int
 
@@ -274,6 +276,12 @@ class Solver:
     def step_timed(self, nsteps: int) -> float:
         ms = C.c_double()
         self._chk(self._f("step_timed")(self._h, nsteps, C.byref(ms)), "step_timed")
+        return ms.value
+
+    def steps_timed(self, nsteps: int, nlaunches: int) -> float:
+        """nlaunches launches of nsteps steps each, enqueued back to back; device time of the whole sequence [ms]"""
+        ms = C.c_double()
+        self._chk(self._f("steps_timed")(self._h, nsteps, nlaunches, C.byref(ms)), "steps_timed")
         return ms.value
 
     def synchronize(self):

@@ -16,7 +16,7 @@
 
 #include "samsim_device.h"
 
-extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, hipStream_t stream);
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, long long grid, hipStream_t stream);
 
 namespace {
 
@@ -41,6 +41,16 @@ struct samsim_handle {
   long long ncol = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  // A step of a large ensemble is two launches: the first 5/8 of the 64-column blocks on `stream`, the rest on `stream2`.  Columns
+  // never meet, so each part only follows its own previous launch; the workgroups of a launch finish raggedly (the last of the
+  // four rounds of a 16 384-block launch leaves the chip partly idle for 15 % of a workgroup's run time), and with two unequal
+  // parts in flight the tail of one is filled by the other instead of by nothing.  Every other entry point waits for both.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t fork = nullptr;      // recorded on `stream` when other work was enqueued there since the last launch: stream2 waits for it
+  bool other_work = true;
+  int split_eighths = 5;          // share of the first part in eighths (SAMSIM_SPLIT_EIGHTHS overrides: tuning runs)
+  long long split_blocks = 8192;  // a launch of at least this many 64-column blocks is split (SAMSIM_SPLIT_BLOCKS overrides: tests, 0 = never)
+  hipEvent_t ev0b = nullptr, ev1b = nullptr;
   // device memory
   double *lay = nullptr, *scal = nullptr;
   int32_t *n_active = nullptr, *status = nullptr, *err_layer = nullptr;
@@ -221,36 +231,57 @@ int launch(samsim_handle *h, long long nsteps) {
   // boundflux_flag 2): no launch without them, whatever the other flags say
   if (launch_needs_forcing(h->cfg) && (!h->f_sw || !h->f_lw || !h->f_T2m || !h->f_precip || h->flen < 2)) return SAMSIM_ERR_ARG;
   if (h->cfg.bgc_flag == 2 && h->n_bgc < 1) return SAMSIM_ERR_ARG;   // samsim_set_tracers first
-  const int s = h->slot;
-  h->slot = (h->slot + 1) % kRing;
-  HIPCHK(hipEventSynchronize(h->slot_done[s]));
-  DevParams &p = h->h_params[s];
-  p.cfg = h->cfg;
-  p.lay = h->lay; p.scal = h->scal; p.n_active = h->n_active; p.status = h->status; p.err_layer = h->err_layer;
-  p.err_step = h->err_step; p.work = h->work;
-  p.spec = h->spec; p.flags = h->flags;
-  p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
-  p.nsites = h->nsites; p.site = h->site;
-  p.ocean_dflq = h->ocean_dflq; p.ocean_sbu = h->ocean_sbu;
-  p.ncol = h->ncol;
-  p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
-  p.nsteps = nsteps;
-  p.out_lay = h->out_lay; p.out_scal = h->out_scal; p.out_n_active = h->out_n_active;
-  p.out_col0 = h->out_col0; p.out_ncols = h->out_ncols;
-  p.p17 = h->p17; p.p14 = h->p14; p.tf_c3 = h->tf_c3;
-  p.bgc = h->bgc; p.bgc_bot = h->bgc_bot; p.bfl = h->bfl; p.out_bgc = h->out_bgc; p.out_bgc_bot = h->out_bgc_bot;
-  p.n_bgc = h->n_bgc; p.bgc_total0 = h->bgc_total0;
-  HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(samsim_launch_step(&h->d_params[s], &p, h->stream));
-  HIPCHK(hipEventRecord(h->slot_done[s], h->stream));
+  const long long nblk = (h->ncol + 63) / 64;
+  // two parts from 8 192 blocks up (two rounds of the chip's 4 096 wave slots): below that a launch has no rounds to speak of
+  // (nblkA < nblk whenever nblk >= 2)
+  const long long nblkA = (h->stream2 && h->split_blocks > 0 && nblk >= h->split_blocks && nblk >= 2) ? (nblk * h->split_eighths + 7) / 8 : nblk;
+  if (nblkA < nblk && h->other_work) {
+    HIPCHK(hipEventRecord(h->fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->fork, 0));
+  }
+  h->other_work = false;
+  for (int part = 0; part < 2; ++part) {
+    const long long b0 = part == 0 ? 0 : nblkA, nb = part == 0 ? nblkA : nblk - nblkA;
+    if (nb <= 0) continue;
+    hipStream_t st = part == 0 ? h->stream : h->stream2;
+    const int s = h->slot;
+    h->slot = (h->slot + 1) % kRing;
+    HIPCHK(hipEventSynchronize(h->slot_done[s]));
+    DevParams &p = h->h_params[s];
+    p.cfg = h->cfg;
+    p.lay = h->lay; p.scal = h->scal; p.n_active = h->n_active; p.status = h->status; p.err_layer = h->err_layer;
+    p.err_step = h->err_step; p.work = h->work;
+    p.spec = h->spec; p.flags = h->flags;
+    p.f_sw = h->f_sw; p.f_lw = h->f_lw; p.f_T2m = h->f_T2m; p.f_precip = h->f_precip; p.flen = h->flen;
+    p.nsites = h->nsites; p.site = h->site;
+    p.ocean_dflq = h->ocean_dflq; p.ocean_sbu = h->ocean_sbu;
+    p.ncol = h->ncol;
+    p.block0 = b0;
+    p.time0 = h->clk.time; p.step0 = h->clk.step; p.n_time_out0 = h->clk.n_time_out; p.time_counter0 = h->clk.time_counter;
+    p.nsteps = nsteps;
+    p.out_lay = h->out_lay; p.out_scal = h->out_scal; p.out_n_active = h->out_n_active;
+    p.out_col0 = h->out_col0; p.out_ncols = h->out_ncols;
+    p.p17 = h->p17; p.p14 = h->p14; p.tf_c3 = h->tf_c3;
+    p.bgc = h->bgc; p.bgc_bot = h->bgc_bot; p.bfl = h->bfl; p.out_bgc = h->out_bgc; p.out_bgc_bot = h->out_bgc_bot;
+    p.n_bgc = h->n_bgc; p.bgc_total0 = h->bgc_total0;
+    HIPCHK(hipMemcpyAsync(&h->d_params[s], &p, sizeof(DevParams), hipMemcpyHostToDevice, st));
+    HIPCHK(samsim_launch_step(&h->d_params[s], &p, nb, st));
+    HIPCHK(hipEventRecord(h->slot_done[s], st));
+  }
   h->stepped = true;
   advance_clock(h, nsteps);
   return SAMSIM_OK;
 }
 
-int use(samsim_handle *h) {
+// every entry point but the stepping ones waits for the second stream and makes the next launch's second part wait for whatever
+// it leaves on the first
+int use(samsim_handle *h, bool stepping = false) {
   if (!h) return SAMSIM_ERR_ARG;
   HIPCHK(hipSetDevice(h->device));
+  if (!stepping) {
+    if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+    h->other_work = true;
+  }
   return SAMSIM_OK;
 }
 
@@ -291,12 +322,17 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   samsim_handle *h = new (std::nothrow) samsim_handle();
   if (!h) return SAMSIM_ERR_NOMEM;
   h->cfg = *cfg; h->ncol = ncol; h->device = device;
+  if (const char *e = std::getenv("SAMSIM_SPLIT_BLOCKS")) h->split_blocks = std::atoll(e);
+  if (const char *e = std::getenv("SAMSIM_SPLIT_EIGHTHS")) { const int v = std::atoi(e); if (v >= 1 && v <= 7) h->split_eighths = v; }
   h->clk = samsim_clock{0.0, 0, 0, 1, 0};
   h->p17 = std::pow(10.0, -17.0);
   h->p14 = std::pow(10.0, -14.0);
   h->tf_c3 = (double)(5.33f * std::pow(10.0f, -7.0f));
   const size_t N = (size_t)cfg->nlayer, nc = (size_t)ncol;
   bool ok = hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
+  ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking), "hipStreamCreate");
+  ok = ok && hip_ok(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate");
+  ok = ok && hip_ok(hipEventCreate(&h->ev0b), "hipEventCreate") && hip_ok(hipEventCreate(&h->ev1b), "hipEventCreate");
   ok = ok && hip_ok(dalloc(&h->lay, DEV_LAY_DOUBLES(N, nc)), "hipMalloc lay");
   ok = ok && hip_ok(dalloc(&h->scal, (size_t)SAMSIM_NSCAL * nc), "hipMalloc scal");
   ok = ok && hip_ok(dalloc(&h->n_active, nc), "hipMalloc n_active");
@@ -346,6 +382,7 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
 void samsim_destroy(samsim_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
@@ -359,6 +396,10 @@ void samsim_destroy(samsim_handle *h) {
   for (int i = 0; i < kRing; ++i) if (h->slot_done[i]) (void)hipEventDestroy(h->slot_done[i]);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->fork) (void)hipEventDestroy(h->fork);
+  if (h->ev0b) (void)hipEventDestroy(h->ev0b);
+  if (h->ev1b) (void)hipEventDestroy(h->ev1b);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -511,26 +552,34 @@ int samsim_get_clock(samsim_handle *h, samsim_clock *c) {
 }
 
 int samsim_step(samsim_handle *h, int64_t nsteps) {
-  int rc = use(h);
+  int rc = use(h, true);
   if (rc) return rc;
   if (nsteps < 0) return SAMSIM_ERR_ARG;
   return launch(h, nsteps);
 }
 
-int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms) {
-  int rc = use(h);
+int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, double *device_ms) {
+  int rc = use(h);   // (waits for the second stream: the timed region starts with both streams idle or ordered behind ev0)
   if (rc) return rc;
-  if (nsteps < 0 || !kernel_ms) return SAMSIM_ERR_ARG;
+  if (nsteps < 0 || nlaunches < 1 || !device_ms) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  rc = launch(h, nsteps);
-  if (rc) return rc;
+  for (int32_t i = 0; i < nlaunches; ++i) {
+    rc = launch(h, nsteps);
+    if (rc) return rc;
+  }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventRecord(h->ev1b, h->stream2));
   HIPCHK(hipEventSynchronize(h->ev1));
-  float ms = 0.f;
+  HIPCHK(hipEventSynchronize(h->ev1b));
+  float ms = 0.f, msb = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  *kernel_ms = (double)ms;
+  HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1b));   // (the second stream's first launch is ordered behind ev0 by the fork event)
+  *device_ms = (double)(ms > msb ? ms : msb);
   return SAMSIM_OK;
 }
+
+int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms) { return samsim_steps_timed(h, nsteps, 1, kernel_ms); }
 
 int samsim_synchronize(samsim_handle *h) {
   int rc = use(h);

@@ -59,9 +59,10 @@ enum dev_bgc_flux {
 // per-column flag bits
 #define COLF_DIRTY 1    // prognostic layers changed since the last up sweep: the next step runs the full S1 sweep
 #define COLF_RESTART 2  // first step after samsim_set_state: RAY holds the previous Rayleigh numbers
+#define COLF_REGRID 8   // layer_dynamics changed the grid in the previous step: the full first sweep checks the thickness rule again
 #define COLF_REGULAR 4  // the thicknesses of layers 2..N_active follow the grid rule (thick_0, and one common value in the middle
-                        // block): the fused sweeps take them from two loaded values instead of the array (checked by the full first
-                        // sweep, i.e. after samsim_set_state and after every regrid; layer_dynamics preserves it)
+                        // block): the sweeps take them from two loaded values instead of the array (checked by the full first
+                        // sweep after samsim_set_state and after every regrid)
 
 struct DevParams {
   samsim_config cfg;
@@ -81,6 +82,9 @@ struct DevParams {
   const double *ocean_dflq;     // [ncol] offset on the oceanic heat flux of sub_test4, or null (samsim_set_ocean)
   const double *ocean_sbu;      // [ncol] salinity of the water below each column (tank_flag 1), or null
   long long ncol;
+  // this launch's share of the columns: 64-column blocks [block0, block0 + grid) (a step of a large ensemble is two launches on two
+  // streams, samsim_capi.cpp launch())
+  long long block0;
   // uniform clock at launch (mo_data: time, i, n_time_out, time_counter)
   double time0;
   long long step0;

@@ -274,6 +274,10 @@ struct Col {
 #ifndef RARE_CHUNK
 #define RARE_CHUNK 8
 #endif
+// SAMSIM_UAHEAD: how many layers ahead of the arithmetic the fused up sweep requests its operands (2 or 3)
+#ifndef SAMSIM_UAHEAD
+#define SAMSIM_UAHEAD 2
+#endif
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
@@ -623,6 +627,14 @@ __device__ __forceinline__ double thick_by_rule(int k, int n_top, int n_middle, 
   return (k > n_top && k <= n_top + n_middle) ? th_mid : thick_0;
 }
 
+// The thickness of layer kk for the sweeps of the melt season: from the grid rule where the column follows it, else from the array
+struct ThickRule { bool reg; int n_top, n_middle; double th_mid, thick_0; };
+#define THICK_RULE_INIT(tr)                                                                                   \
+  ThickRule tr;                                                                                               \
+  tr.reg = SAMSIM_THICK_RULE && (c.flags & COLF_REGULAR) != 0; tr.n_top = x.p->cfg.n_top; tr.n_middle = x.p->cfg.n_middle; \
+  tr.thick_0 = x.p->cfg.thick_0; tr.th_mid = LAY(SAMSIM_A_THICK, tr.n_top + 1)
+#define THICK_AT(tr, kk) ((tr.reg && (kk) >= 2) ? thick_by_rule(kk, tr.n_top, tr.n_middle, tr.th_mid, tr.thick_0) : LAY(SAMSIM_A_THICK, kk))
+
 // Does row k of the Rayleigh-number array hold this column's current value?  Row 1 is written by the first sweep of every step
 // (prologue_top_layer / sweep_thermo_expulsion), the other rows by the last up sweep where flagged (Ctx::rflag), and all of them by
 // this step's full first sweep.  A row that was not written held no value above ray_crit in any column of the wave.
@@ -639,13 +651,14 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
   double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? CL(m_snow) : 0.0;
   double A = 0.0, G = 0.0;
+  THICK_RULE_INIT(tr);
   // (rows are requested a chunk at a time -- see RARE_CHUNK -- and summed in the reference's order)
   for (int k0 = 1; k0 <= Na; k0 += RARE_CHUNK) {
     double th_[RARE_CHUNK], ps_[RARE_CHUNK], pg_[RARE_CHUNK];
 #pragma unroll
     for (int i = 0; i < RARE_CHUNK; ++i) {
       const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
-      th_[i] = LAY(SAMSIM_A_THICK, kk); ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
+      th_[i] = THICK_AT(tr, kk); ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
     }
 #pragma unroll
     for (int i = 0; i < RARE_CHUNK; ++i) {
@@ -665,7 +678,7 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
 #pragma unroll
       for (int i = 0; i < RARE_CHUNK; ++i) {
         const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
-        m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = LAY(SAMSIM_A_THICK, kk);
+        m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = THICK_AT(tr, kk);
         ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
       }
 #pragma unroll
@@ -980,39 +993,49 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1) LAYU(SAMSIM_A_RAY, Na) = 0.0;
-  // operands requested two layers ahead of the arithmetic, unconditionally and from a clamped row, as in sweep_up_fused
+  // operands requested two layers ahead of the arithmetic, unconditionally and from a clamped row, as in sweep_up_fused.
+  // The thickness rule (COLF_REGULAR) is checked against the array after samsim_set_state and after a regrid; in between -- the
+  // steps of a melt season, which take this sweep because flush3 rewrites every layer -- nothing touches the thicknesses below
+  // layer 1 and a regular column's come from the rule.  Decided per wave, so that the loop's requests stay unconditional.
   struct L4 { double H, m, th, S; };
-  auto ld = [&](int j) -> L4 {
-    L4 r;
-    r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.th = LAYU(SAMSIM_A_THICK, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
-    return r;
-  };
-  L4 cur = ld(Na), nxt = ld(Na >= 2 ? Na - 1 : 1), nn = nxt;
   bool regular = true;
   const double th_mid_rule = LAYU(SAMSIM_A_THICK, g.n_top + 1);
+  const bool check_col = !SAMSIM_THICK_RULE || (c.flags & COLF_REGULAR) == 0 || (c.flags & (COLF_RESTART | COLF_REGRID)) != 0;
+  const bool check_wave = __ballot(check_col) != 0ull;
   const int kmax = wave_max(Na);
-  for (int k = kmax; k >= 1; --k) {
-    if (k > Na) continue;
-    nn = ld(k >= 3 ? k - 2 : 1);
-    const double H_abs = cur.H, m = cur.m, thick = cur.th;
-    if (k >= 2 && thick != thick_by_rule(k, g.n_top, g.n_middle, th_mid_rule, g.thick_0)) regular = false;
-    double S_abs = cur.S;
-    cur = nxt; nxt = nn;
-    if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
-      S_abs = 0.0;
-      LAYU(SAMSIM_A_S_ABS, k) = S_abs;
+  auto run = [&](auto check_tag) {
+    constexpr bool CHECK = decltype(check_tag)::value;
+    auto ld = [&](int j) -> L4 {
+      L4 r;
+      r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
+      r.th = (CHECK || j < 2) ? LAYU(SAMSIM_A_THICK, j) : thick_by_rule(j, g.n_top, g.n_middle, th_mid_rule, g.thick_0);
+      return r;
+    };
+    L4 cur = ld(Na), nxt = ld(Na >= 2 ? Na - 1 : 1), nn = nxt;
+    for (int k = kmax; k >= 1; --k) {
+      if (k > Na) continue;
+      nn = ld(k >= 3 ? k - 2 : 1);
+      const double H_abs = cur.H, m = cur.m, thick = cur.th;
+      if (CHECK && k >= 2 && thick != thick_by_rule(k, g.n_top, g.n_middle, th_mid_rule, g.thick_0)) regular = false;
+      double S_abs = cur.S;
+      cur = nxt; nxt = nn;
+      if (S_abs < 0.0) {  // health check of the previous step, mo_grotz.f90:812-818 (element-wise clamp)
+        S_abs = 0.0;
+        LAYU(SAMSIM_A_S_ABS, k) = S_abs;
+      }
+      double S_bu, H;
+      per_mass(S_abs, H_abs, m, S_bu, H);
+      double T, phi = 0.0;
+      int rr = getT(s, H, S_bu, T_test, T, phi);
+      if (rr && !rc) { rc = rr; rc_layer = k; }
+      T_test = T;
+      // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
+      LAYU(SAMSIM_A_T, k) = T;
+      LAYU(SAMSIM_A_PHI, k) = phi;
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
     }
-    double S_bu, H;
-    per_mass(S_abs, H_abs, m, S_bu, H);
-    double T, phi = 0.0;
-    int rr = getT(s, H, S_bu, T_test, T, phi);
-    if (rr && !rc) { rc = rr; rc_layer = k; }
-    T_test = T;
-    // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
-    LAYU(SAMSIM_A_T, k) = T;
-    LAYU(SAMSIM_A_PHI, k) = phi;
-    s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
-  }
+  };
+  if (check_wave) run(std::true_type{}); else run(std::false_type{});
   c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   c.flags = regular ? (c.flags | COLF_REGULAR) : (c.flags & ~COLF_REGULAR);
@@ -1060,12 +1083,13 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
   // rows are requested a chunk at a time (see RARE_CHUNK)
   constexpr int CH = RARE_CHUNK / 2;
+  THICK_RULE_INIT(tr);
   for (int k0 = 1; k0 <= Na; k0 += CH) {
     double m_[CH], th_[CH], T_[CH], H_[CH], S_[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
-      m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = LAY(SAMSIM_A_THICK, kk); T_[i] = LAY(SAMSIM_A_T, kk);
+      m_[i] = LAY(SAMSIM_A_M, kk); th_[i] = THICK_AT(tr, kk); T_[i] = LAY(SAMSIM_A_T, kk);
       H_[i] = LAY(SAMSIM_A_H_ABS, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk);
     }
 #pragma unroll
@@ -1334,6 +1358,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
   // operands of a chunk of layers are requested together (see RARE_CHUNK); what only a draining layer reads is loaded there.
   constexpr int CH = RARE_CHUNK / 2;
   const int N = c.N;
+  THICK_RULE_INIT(tr);
   L cur = {0, 0, 0, 0, 0, 0, false};
   double flup_prev = 0.0;  // fl_up(k-1) = fl_m(k)
   for (int j0 = 1; j0 <= Na + 1; j0 += CH) {
@@ -1342,7 +1367,7 @@ __device__ RARE void sweep_grav_drain(Col &c, const Ctx &x, bool do_beer, double
     for (int i = 0; i < CH; ++i) {
       const int kk = (j0 + i <= N) ? j0 + i : N;
       T_[i] = LAY(SAMSIM_A_T, kk); Sbu_[i] = LAY(SAMSIM_A_S_BU, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk);
-      H_[i] = LAY(SAMSIM_A_H_ABS, kk); th_[i] = LAY(SAMSIM_A_THICK, kk); Sbr_[i] = LAY(SAMSIM_A_S_BR, kk);
+      H_[i] = LAY(SAMSIM_A_H_ABS, kk); th_[i] = THICK_AT(tr, kk); Sbr_[i] = LAY(SAMSIM_A_S_BR, kk);
     }
     Sbr_[CH] = LAY(SAMSIM_A_S_BR, (j0 + CH <= N) ? j0 + CH : N);
 #pragma unroll
@@ -1447,12 +1472,13 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
     double hr_up = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
     double flq_k = 0.0;   // fl_Q(k)
     constexpr int CH = RARE_CHUNK / 2;   // five operands per layer (rows requested a chunk at a time, see RARE_CHUNK)
+    THICK_RULE_INIT(tr);
     for (int k0 = 2; k0 <= Na; k0 += CH) {
       double T_[CH], th_[CH], ps_[CH], pl_[CH], Hm_[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int kk = (k0 + i <= N) ? k0 + i : N;
-        T_[i] = LAY(SAMSIM_A_T, kk); th_[i] = LAY(SAMSIM_A_THICK, kk);
+        T_[i] = LAY(SAMSIM_A_T, kk); th_[i] = THICK_AT(tr, kk);
         ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pl_[i] = LAY(SAMSIM_A_PSI_L, kk);
         Hm_[i] = LAY(SAMSIM_A_H_ABS, kk - 1);    // layer k-1 (kk >= 2), finished when layer k's flux is known
       }
@@ -1952,6 +1978,10 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     return r;
   };
   UL cur = load_ul(Na), nxt = load_ul(Na >= 2 ? Na - 1 : 1), nn = nxt;   // layers k, k-1, k-2
+#if SAMSIM_UAHEAD == 3
+  nn = load_ul(Na >= 3 ? Na - 2 : 1);
+  UL n3 = nn;                                                              // layer k-3
+#endif
   bool alive = true;
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
   // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
@@ -2019,9 +2049,15 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     ISA_MARK("U_ITER_BEGIN");
     ST_MARK(ST_UP);
     if (k > Na) continue;
+#if SAMSIM_UAHEAD == 3
+    n3 = load_ul(k >= 4 ? k - 3 : 1);
+    body(k, std::false_type{});
+    cur = nxt; nxt = nn; nn = n3;
+#else
     nn = load_ul(k >= 3 ? k - 2 : 1);
     body(k, std::false_type{});
     cur = nxt; nxt = nn;
+#endif
     ISA_MARK("U_ITER_END");
   }
   body(1, std::true_type{});
@@ -2070,10 +2106,11 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
   const double dt = g.dt;
   // horizontal flow length = total thickness (mo_flush.f90:104)
   double cnst = 0.0;
+  THICK_RULE_INIT(tr);
   for (int k0 = 1; k0 <= Na; k0 += 2 * RARE_CHUNK) {   // (rows requested a chunk at a time, see RARE_CHUNK)
     double th_[2 * RARE_CHUNK];
 #pragma unroll
-    for (int i = 0; i < 2 * RARE_CHUNK; ++i) th_[i] = LAY(SAMSIM_A_THICK, (k0 + i <= N) ? k0 + i : N);
+    for (int i = 0; i < 2 * RARE_CHUNK; ++i) { const int kk = (k0 + i <= N) ? k0 + i : N; th_[i] = THICK_AT(tr, kk); }
 #pragma unroll
     for (int i = 0; i < 2 * RARE_CHUNK; ++i) if (k0 + i <= Na) cnst += th_[i];
   }
@@ -2091,7 +2128,7 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
 #pragma unroll
     for (int i = 0; i < RARE_CHUNK; ++i) {
       const int kk = (k0 - i >= 1) ? k0 - i : 1;
-      th_[i] = LAY(SAMSIM_A_THICK, kk); pl_[i] = LAY(SAMSIM_A_PSI_L, kk);
+      th_[i] = THICK_AT(tr, kk); pl_[i] = LAY(SAMSIM_A_PSI_L, kk);
       pg_[i] = (CFG(snow_flush_flag) == 1) ? LAY(SAMSIM_A_PSI_G, kk) : 0.0;
     }
 #pragma unroll
@@ -2135,7 +2172,7 @@ __device__ RARE void flush3(Col &c, const Ctx &x) {
 #pragma unroll
     for (int i = 0; i < CH2; ++i) {
       const int kk = (k0 + i <= N) ? k0 + i : N, kn = (kk + 1 <= N) ? kk + 1 : N;
-      th_[i] = LAY(SAMSIM_A_THICK, kk); pe_[i] = LAY(SAMSIM_A_PERM, kk); T_[i] = LAY(SAMSIM_A_T, kk);
+      th_[i] = THICK_AT(tr, kk); pe_[i] = LAY(SAMSIM_A_PERM, kk); T_[i] = LAY(SAMSIM_A_T, kk);
       m_[i] = LAY(SAMSIM_A_M, kk); S_[i] = LAY(SAMSIM_A_S_ABS, kk); H_[i] = LAY(SAMSIM_A_H_ABS, kk);
       Rn_[i] = LAY(D_V_EX, kn); fvv_[i] = LAY(SAMSIM_A_FLUSH_V, kk); fhh_[i] = LAY(SAMSIM_A_FLUSH_H, kk);
     }
@@ -2977,7 +3014,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
         th1 / g.thick_0 < 0.5) {
       ST_COUNT(CT_L_REGRID, (unsigned long long)__popcll(__ballot(1)));
       layer_dynamics<K>(c, x);
-      c.flags |= COLF_DIRTY;
+      c.flags |= COLF_DIRTY | COLF_REGRID;
       if (c.status) return;
     }
     Na = c.Na;
@@ -2992,7 +3029,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   } else {
     if (LAY(SAMSIM_A_PHI, 1) > psi_s_min) {
       layer_dynamics<K>(c, x);
-      c.flags |= COLF_DIRTY;
+      c.flags |= COLF_DIRTY | COLF_REGRID;
       if (c.status) return;
     }
   }
@@ -3022,7 +3059,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
                                                                         double *__restrict__ bfl, double *__restrict__ out_bgc,
                                                                         double *__restrict__ out_bgc_bot, const int32_t *__restrict__ site) {
   const DevParams &p = *pp;
-  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long blk = (long long)blockIdx.x + p.block0;
+  const long long col = blk * blockDim.x + threadIdx.x;
   if (col >= p.ncol) return;
   Ctx x;
   x.p = pp;
@@ -3052,7 +3090,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
 #endif
   Col c;
 #if SAMSIM_BLOCKED
-  c.lay = (gdouble *)((gchar *)lay + (size_t)blockIdx.x * ((size_t)p.cfg.nlayer * DEV_ROWB) + 4096);
+  c.lay = (gdouble *)((gchar *)lay + (size_t)blk * ((size_t)p.cfg.nlayer * DEV_ROWB) + 4096);
 #else
   c.lay = (gdouble *)lay;
 #endif
@@ -3171,9 +3209,8 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
 }  // namespace
 
 // d_params: device copy of the parameter block `hp` (host copy, used here for the direct pointer arguments)
-extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, hipStream_t stream) {
+extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevParams *hp, long long grid, hipStream_t stream) {
   const int block = SAMSIM_BLOCK;
-  const long long grid = (hp->ncol + block - 1) / block;
   const samsim_config &g = hp->cfg;
   // one instantiation per flag set; tracers (bgc_flag 2) and several forcing sets / oceans select their own
   const bool tracers = g.bgc_flag == 2, sites = hp->nsites > 1 || hp->ocean_dflq || hp->ocean_sbu;

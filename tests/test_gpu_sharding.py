@@ -137,3 +137,19 @@ def test_a_column_does_not_depend_on_its_wave_mates():
 def bench_scalar_index(name):
     from samsim_amd.capi import SCALARS
     return list(SCALARS).index(name)
+
+
+def test_a_step_split_over_two_streams_equals_the_single_launch(monkeypatch):
+    """A step of a large ensemble (>= 8 192 column blocks) is two launches on two streams, 5/8 and 3/8 of the blocks; here the
+    threshold is lowered so that a 1 000-column ensemble splits.  Several steps back to back (no wait in between), output
+    snapshot and status included, must equal the unsplit run bit for bit."""
+    import samsim_amd
+    from tests.shard_worker import ensemble_shard
+    results = []
+    for split in ("0", "2"):
+        monkeypatch.setenv("SAMSIM_SPLIT_BLOCKS", split)
+        st, status = ensemble_shard(0, 1000, 260, launches=4)
+        results.append((st, status))
+    (a, xa), (b, xb) = results
+    assert np.array_equal(xa, xb) and not xa.any()
+    assert np.array_equal(a.lay[:10], b.lay[:10]) and np.array_equal(a.scal, b.scal) and np.array_equal(a.n_active, b.n_active)
