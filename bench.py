@@ -372,7 +372,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "samsim_step_kernel", "mean_launch_ms": mean_ms,
                          "how": "HIP events around the K back-to-back steps on the launch streams, / K; a step of >= 8192 column "
-                                "blocks is two concurrent launches (5/8 and 3/8 of the columns on two streams)",
+                                "blocks is two concurrent launches (half of the columns each, on two streams)",
                          "algorithmic_bytes_per_launch": bytes_per_colstep * ncol * args.substeps,
                          "lib_md5": lib_md5()},
         }

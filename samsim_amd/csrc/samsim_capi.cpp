@@ -41,14 +41,15 @@ struct samsim_handle {
   long long ncol = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  // A step of a large ensemble is two launches: the first 5/8 of the 64-column blocks on `stream`, the rest on `stream2`.  Columns
+  // A step of a large ensemble is two launches: the first half of the 64-column blocks on `stream`, the rest on `stream2`.  Columns
   // never meet, so each part only follows its own previous launch; the workgroups of a launch finish raggedly (the last of the
-  // four rounds of a 16 384-block launch leaves the chip partly idle for 15 % of a workgroup's run time), and with two unequal
-  // parts in flight the tail of one is filled by the other instead of by nothing.  Every other entry point waits for both.
+  // four rounds of a 16 384-block launch leaves the chip partly idle for 15 % of a workgroup's run time), and with two launches
+  // in flight per step, and the next step's enqueued behind them, a draining launch is topped up by the others.  Every other entry point waits for both.
   hipStream_t stream2 = nullptr;
   hipEvent_t fork = nullptr;      // recorded on `stream` when other work was enqueued there since the last launch: stream2 waits for it
   bool other_work = true;
-  int split_eighths = 5;          // share of the first part in eighths (SAMSIM_SPLIT_EIGHTHS overrides: tuning runs)
+  int split_eighths = 4;          // share of the first part in eighths (SAMSIM_SPLIT_EIGHTHS overrides: tuning runs; 4, 5, 6, 7 eighths
+                                  // measured 962, 973, 968, 992 ms per 500-step step of 1 048 576 columns, one launch 1 009 ms)
   long long split_blocks = 8192;  // a launch of at least this many 64-column blocks is split (SAMSIM_SPLIT_BLOCKS overrides: tests, 0 = never)
   hipEvent_t ev0b = nullptr, ev1b = nullptr;
   // device memory

@@ -140,7 +140,7 @@ def bench_scalar_index(name):
 
 
 def test_a_step_split_over_two_streams_equals_the_single_launch(monkeypatch):
-    """A step of a large ensemble (>= 8 192 column blocks) is two launches on two streams, 5/8 and 3/8 of the blocks; here the
+    """A step of a large ensemble (>= 8 192 column blocks) is two launches on two streams, half of the blocks each; here the
     threshold is lowered so that a 1 000-column ensemble splits.  Several steps back to back (no wait in between), output
     snapshot and status included, must equal the unsplit run bit for bit."""
     import samsim_amd

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--substeps", type=int, default=20)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--kernel", default="samsim_step_kernel")
+    ap.add_argument("--parts", type=int, default=2,
+                    help="launches of the kernel per step (a step of a large ensemble is two concurrent launches on two streams): the "
+                         "counters of the parts are added, the step time is taken from the first start to the last end of its parts")
     a = ap.parse_args()
     out = {"kernel": a.kernel, "ncol": a.ncol, "nlayer": a.nlayer, "timesteps_per_launch": a.substeps}
     if a.lib and os.path.exists(a.lib):
@@ -42,14 +45,29 @@ def main():
                 out.setdefault("lds_block_bytes", int(r["LDS_Block_Size"]))
                 out.setdefault("scratch_bytes_per_lane", int(r["Scratch_Size"]))
             for n, d in per_dispatch.items():
-                counters[n] = {"median": statistics.median(d.values()), "launches": len(d)}
-    out["counters_per_launch"] = counters
+                ids = sorted(d, key=lambda k: int(k))
+                steps = [sum(d[i] for i in ids[j:j + a.parts]) for j in range(0, len(ids) - a.parts + 1, a.parts)]
+                counters[n] = {"median": statistics.median(steps), "launches": len(ids), "steps": len(steps)}
+    out["launches_per_step"] = a.parts
+    out["counters_per_launch"] = counters   # (per step: the sum over the launches of a step)
     for f in glob.glob(os.path.join(a.dir, "**", "*_kernel_stats.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if a.kernel in r["Name"]:
-                    out["kernel_trace"] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6,
+                    out["kernel_stats"] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6,
                                            "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
+    # one step = a.parts consecutive dispatches of the kernel: from the first start to the last end
+    for f in glob.glob(os.path.join(a.dir, "**", "*_kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            rows = [(int(r["Dispatch_Id"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(fh)
+                    if a.kernel in r["Kernel_Name"]]
+        rows.sort()
+        steps = [rows[j:j + a.parts] for j in range(0, len(rows) - a.parts + 1, a.parts)]
+        if steps:
+            dur = [(max(e for _, _, e in st) - min(b for _, b, _ in st)) / 1e6 for st in steps]
+            span = (max(e for _, _, e in rows) - min(b for _, b, _ in rows)) / 1e6
+            out["kernel_trace"] = {"steps": len(steps), "average_ms": sum(dur) / len(dur), "min_ms": min(dur), "max_ms": max(dur),
+                                   "first_start_to_last_end_per_step_ms": span / len(steps)}
     cells = a.ncol * a.nlayer * a.substeps
     waves_cells = cells / 64.0
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
