@@ -20,7 +20,8 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
 
 namespace {
 
-constexpr int kRing = 8;
+constexpr int kRing = 16;
+constexpr int kMaxParts = 4;
 
 thread_local char g_last_hip_error[256] = "";
 
@@ -46,6 +47,9 @@ struct samsim_handle {
   // four rounds of a 16 384-block launch leaves the chip partly idle for 15 % of a workgroup's run time), and with two launches
   // in flight per step, and the next step's enqueued behind them, a draining launch is topped up by the others.  Every other entry point waits for both.
   hipStream_t stream2 = nullptr;
+  hipStream_t streamx[kMaxParts - 2]{};   // further streams when SAMSIM_SPLIT_PARTS asks for more than two parts (tuning runs)
+  hipEvent_t ev1x[kMaxParts - 2]{};
+  int split_parts = 2;
   hipEvent_t fork = nullptr;      // recorded on `stream` when other work was enqueued there since the last launch: stream2 waits for it
   bool other_work = true;
   int split_eighths = 4;          // share of the first part in eighths (SAMSIM_SPLIT_EIGHTHS overrides: tuning runs; 4, 5, 6, 7 eighths
@@ -234,17 +238,25 @@ int launch(samsim_handle *h, long long nsteps) {
   if (h->cfg.bgc_flag == 2 && h->n_bgc < 1) return SAMSIM_ERR_ARG;   // samsim_set_tracers first
   const long long nblk = (h->ncol + 63) / 64;
   // two parts from 8 192 blocks up (two rounds of the chip's 4 096 wave slots): below that a launch has no rounds to speak of
-  // (nblkA < nblk whenever nblk >= 2)
-  const long long nblkA = (h->stream2 && h->split_blocks > 0 && nblk >= h->split_blocks && nblk >= 2) ? (nblk * h->split_eighths + 7) / 8 : nblk;
-  if (nblkA < nblk && h->other_work) {
+  const bool split = h->stream2 && h->split_blocks > 0 && nblk >= h->split_blocks && nblk >= h->split_parts;
+  const int nparts = split ? h->split_parts : 1;
+  auto stream_of = [&](int part) { return part == 0 ? h->stream : part == 1 ? h->stream2 : h->streamx[part - 2]; };
+  // part boundaries: the first part takes split_eighths/8 of the blocks when there are two, equal shares otherwise
+  auto bound = [&](int part) -> long long {
+    if (part <= 0) return 0;
+    if (part >= nparts) return nblk;
+    if (nparts == 2) return (nblk * h->split_eighths + 7) / 8;
+    return (nblk * part) / nparts;
+  };
+  if (split && h->other_work) {
     HIPCHK(hipEventRecord(h->fork, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->stream2, h->fork, 0));
+    for (int part = 1; part < nparts; ++part) HIPCHK(hipStreamWaitEvent(stream_of(part), h->fork, 0));
   }
   h->other_work = false;
-  for (int part = 0; part < 2; ++part) {
-    const long long b0 = part == 0 ? 0 : nblkA, nb = part == 0 ? nblkA : nblk - nblkA;
+  for (int part = 0; part < nparts; ++part) {
+    const long long b0 = bound(part), nb = bound(part + 1) - b0;
     if (nb <= 0) continue;
-    hipStream_t st = part == 0 ? h->stream : h->stream2;
+    hipStream_t st = stream_of(part);
     const int s = h->slot;
     h->slot = (h->slot + 1) % kRing;
     HIPCHK(hipEventSynchronize(h->slot_done[s]));
@@ -281,6 +293,7 @@ int use(samsim_handle *h, bool stepping = false) {
   HIPCHK(hipSetDevice(h->device));
   if (!stepping) {
     if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+    for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) HIPCHK(hipStreamSynchronize(h->streamx[i]));
     h->other_work = true;
   }
   return SAMSIM_OK;
@@ -334,6 +347,9 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking), "hipStreamCreate");
   ok = ok && hip_ok(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate");
   ok = ok && hip_ok(hipEventCreate(&h->ev0b), "hipEventCreate") && hip_ok(hipEventCreate(&h->ev1b), "hipEventCreate");
+  if (const char *e = std::getenv("SAMSIM_SPLIT_PARTS")) { const int v = std::atoi(e); if (v >= 2 && v <= kMaxParts) h->split_parts = v; }
+  for (int i = 0; ok && i < h->split_parts - 2; ++i)
+    ok = hip_ok(hipStreamCreateWithFlags(&h->streamx[i], hipStreamNonBlocking), "hipStreamCreate") && hip_ok(hipEventCreate(&h->ev1x[i]), "hipEventCreate");
   ok = ok && hip_ok(dalloc(&h->lay, DEV_LAY_DOUBLES(N, nc)), "hipMalloc lay");
   ok = ok && hip_ok(dalloc(&h->scal, (size_t)SAMSIM_NSCAL * nc), "hipMalloc scal");
   ok = ok && hip_ok(dalloc(&h->n_active, nc), "hipMalloc n_active");
@@ -383,6 +399,7 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
 void samsim_destroy(samsim_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) (void)hipStreamSynchronize(h->streamx[i]);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
@@ -400,6 +417,7 @@ void samsim_destroy(samsim_handle *h) {
   if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->ev0b) (void)hipEventDestroy(h->ev0b);
   if (h->ev1b) (void)hipEventDestroy(h->ev1b);
+  for (int i = 0; i < kMaxParts - 2; ++i) { if (h->ev1x[i]) (void)hipEventDestroy(h->ev1x[i]); if (h->streamx[i]) (void)hipStreamDestroy(h->streamx[i]); }
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -571,12 +589,20 @@ int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, doub
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventRecord(h->ev1b, h->stream2));
+  for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) HIPCHK(hipEventRecord(h->ev1x[i], h->streamx[i]));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventSynchronize(h->ev1b));
   float ms = 0.f, msb = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1b));   // (the second stream's first launch is ordered behind ev0 by the fork event)
-  *device_ms = (double)(ms > msb ? ms : msb);
+  HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1b));   // (the other streams' first launches are ordered behind ev0 by the fork event)
+  if (msb > ms) ms = msb;
+  for (int i = 0; i < kMaxParts - 2; ++i) {
+    if (!h->streamx[i]) continue;
+    HIPCHK(hipEventSynchronize(h->ev1x[i]));
+    HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1x[i]));
+    if (msb > ms) ms = msb;
+  }
+  *device_ms = (double)ms;
   return SAMSIM_OK;
 }
 
