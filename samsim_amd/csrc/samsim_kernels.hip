@@ -278,6 +278,10 @@ struct Col {
 #ifndef SAMSIM_UAHEAD
 #define SAMSIM_UAHEAD 2
 #endif
+// SAMSIM_FUSE_COUPLING: thin-snow coupling inside the fused down sweep (see there); 0 = columns with thin snow take the unfused order
+#ifndef SAMSIM_FUSE_COUPLING
+#define SAMSIM_FUSE_COUPLING 1
+#endif
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
@@ -378,7 +382,9 @@ __device__ __forceinline__ double per_mass(double S_abs, double m) { return S_ab
 // func_S_br without / with the S_bu clamp, mo_thermo_functions.f90:308-360.  flang lowers T**2._wp and T**3._wp
 // to multiplications (verified bit for bit against the flang build), so do we.
 __device__ __forceinline__ double S_br_poly(const Salt &s, double T) {
-#if SAMSIM_HORNER
+#if SAMSIM_HORNER == 2
+  return T * __builtin_fma(T, __builtin_fma(T, s.c4, s.c3), s.c2);   // Horner with fused multiply-adds (one routine for every caller)
+#elif SAMSIM_HORNER
   return T * (s.c2 + T * (s.c3 + T * s.c4));
 #else
   return 0.0 + s.c2 * T + s.c3 * (T * T) + s.c4 * (T * T * T);
@@ -421,8 +427,28 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 #ifndef SAMSIM_NEWTON1
 #define SAMSIM_NEWTON1 1
 #endif
+#ifndef SAMSIM_NEWTON_FMA
+#define SAMSIM_NEWTON_FMA 1
+#endif
 // one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1
 __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
+#if SAMSIM_NEWTON_FMA
+  // the same step with fused multiply-adds (one rounding per a*b+c instead of two: 27 vector instructions instead of 41 per
+  // evaluation, 3.6 evaluations per layer-cell, all on the critical path of the up sweep); each iterate within an ulp or two
+  // of the unfused form's, like the other ulp-level changes of this file
+  const double sbf = T_0 * __builtin_fma(T_0, __builtin_fma(T_0, s.c4, s.c3), s.c2);
+  if (sbf > 0.0001) {
+    const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
+    const double A = __builtin_fma(T_0, __builtin_fma(T_0, 0.5 * c_s_beta, c_s), -latent_heat - H);
+    const double B = __builtin_fma(c_s_beta, T_0, c_s);
+    const double num = __builtin_fma(A, sb2, LS * sbf);
+    const double Tc = T_0 < -20.0 ? -20.0 : T_0;
+    const double dd = __builtin_fma(Tc, __builtin_fma(Tc, 3.0 * s.d4, 2.0 * s.d3), s.d2);
+    const double den = __builtin_fma(B, sb2, -(LS * dd));
+    T_new = T_0 - quot(num, den);
+    return fabs(num) > sb2;
+  }
+#endif
   const double sb = S_br_poly(s, T_0);
 #if SAMSIM_NEWTON1 && SAMSIM_FAST_DIV
   if (sb > 0.0001) {
@@ -707,11 +733,12 @@ __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
 // ---------------------------------------------------------------- snow, mo_snow.f90
 // snow_coupling, mo_snow.f90:61-104.  The reference passes T_snow / T as both the guess and the result of getT;
 // by-reference argument passing makes the guess H/c_l (getT's first statement overwrites it).
+// (core: the top layer's enthalpy, temperature and solid fraction in registers -- the fused down sweep calls it between the
+// brine expulsion and the drainage of layer 1; the wrapper below works on the arrays, as the unfused order and the up sweep do)
 template <class K>
-__device__ RARE void snow_coupling(Col &c, const Ctx &x) {
+__device__ RARE int snow_coupling_core(Col &c, const Ctx &x, double &H_abs, const double m, const double S_bu, double &T, double &phi) {
   const Salt &s = x.salt;
-  double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), S_bu = LAY(SAMSIM_A_S_BU, 1);
-  double T = LAY(SAMSIM_A_T, 1), phi = LAY(SAMSIM_A_PHI, 1), H;
+  double H;
   const double m_snow = CL(m_snow), S_abs_snow = GS(S_ABS_SNOW);
   double phi_sn = GS(PHI_S);
   int rc = 0;
@@ -750,11 +777,17 @@ __device__ RARE void snow_coupling(Col &c, const Ctx &x) {
     if (jj > 200 && fabs(T - CL(T_snow)) > 1.0) rc = 16;
   }
 #undef COUPLE_GETT
+  GS(PHI_S) = phi_sn;
+  return rc ? (rc == 16 ? 16 : 99) : 0;
+}
+template <class K>
+__device__ RARE void snow_coupling(Col &c, const Ctx &x) {
+  double H_abs = LAY(SAMSIM_A_H_ABS, 1), T = LAY(SAMSIM_A_T, 1), phi = LAY(SAMSIM_A_PHI, 1);
+  const int rc = snow_coupling_core<K>(c, x, H_abs, LAY(SAMSIM_A_M, 1), LAY(SAMSIM_A_S_BU, 1), T, phi);
   LAY(SAMSIM_A_H_ABS, 1) = H_abs;
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
-  GS(PHI_S) = phi_sn;
-  if (rc) STOPC(rc == 16 ? 16 : 99, 1);
+  if (rc) STOPC(rc, 1);
 }
 
 
@@ -1512,6 +1545,8 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
 
 template <class K>
 __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x);
+template <class K>
+__device__ __forceinline__ double radiation_header(Col &c, const Ctx &x, double time, int tc);
 
 // ---------------------------------------------------------------- D: fused down sweep (P2 + P3), top -> bottom
 // One pass instead of two for the common step (not the first, not an output step, no thin-snow coupling, no flooding):
@@ -1525,7 +1560,11 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x);
 template <class K>
 // store_default: whether the volume fractions of layers >= 3 are stored when the sweep does not decide itself; decide_psi: it
 // decides after layer 2 (see there), storing them anyway under store_default; surface_done: the sweep evaluated the surface balance
-__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_default, bool decide_psi, bool &surface_done) {
+// couple: this column has a thin snow cover (snow_coupling, mo_grotz.f90:418-420, between the brine expulsion and the drainage);
+// late_rad: some column of the wave has, so the radiation header and the Beer-law pass -- which read the snow temperature the
+// coupling sets -- run inside the sweep, after the top two layers (time, tc, do_beer are theirs)
+__device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_default, bool decide_psi, bool &surface_done,
+                                                 bool couple, bool late_rad, double time, int tc, bool do_beer) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -1545,7 +1584,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // Operands run two iterations ahead of the arithmetic with two request buffers and ONE finished layer: the operands of layer
   // j+2 are requested at the top of iteration j and turned into `raw` at the END of iteration j+1.  (Round 1 and the first half of
   // round 2 finished layer j+1 at the top of iteration j, because the drainage test of B(j) compares S_br(j) with S_br(j+1): one
-  // iteration of lead, a second finished layer -- 18 registers -- held for the sake of a test that is reached in 3 % of the
+  // iteration of lead, a second finished layer -- 18 registers -- held for the sake of a test that is reached in a fifth of the
   // layers.  That test now forms S_br(j+1) from the request buffer on demand.)
   struct Ld { double T, S_abs, m, H_abs, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
@@ -1596,8 +1635,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
   // runs after the loop (once per wave, every lane with its own j), so that the loop body -- the interior layers -- carries
   // neither the bottom-layer work (gas -> ocean water, the bottom turbulence with its exp and two pow) nor its registers.
-  auto layer = [&](const int j, const Ld &below, auto last_tag) {   // below: the request buffer that holds layer j+1
-    constexpr bool LAST = decltype(last_tag)::value;
+  auto layer = [&](const int j, const Ld &below, auto last_tag, auto first_tag) {   // below: the request buffer that holds layer j+1
+    constexpr bool LAST = decltype(last_tag)::value, FIRST = decltype(first_tag)::value;
     // ---- A(j)
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
@@ -1638,6 +1677,20 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     const double SA = S_abs, mA = m;     // S_bu = SA / mA: refreshed bulk salinity, mo_grotz.f90:333-335 (formed where it is read)
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_j = flm_next;
+    // Thin-snow coupling (mo_grotz.f90:418-420) sits between expulsion / mass_transfer and everything below in the reference.  It
+    // reads and writes layer 1 only, and layer 1 is through with the expulsion here (its own flux and the one into layer 2 are
+    // applied), so it runs now, on the registers: the transfers above moved brine at the temperature of the first sweep, the
+    // drainage, the return flow and the conductive flux below see the coupled one -- the unfused order, operation for operation.
+    double Tl = T;
+    if (FIRST && couple) {
+      double phi1 = LAYU(SAMSIM_A_PHI, 1);
+      const double S_bu1 = S_abs / m;   // as sweep_expulsion_transfer stores it (mo_grotz.f90:333), and in the array: the second
+      LAYU(SAMSIM_A_S_BU, 1) = S_bu1;   // coupling of the step (sub_heat_fluxes, in the up sweep's top-layer block) reads it there
+      const int rcc = snow_coupling_core<K>(c, x, H_abs, m, S_bu1, Tl, phi1);
+      LAYU(SAMSIM_A_T, 1) = Tl;
+      LAYU(SAMSIM_A_PHI, 1) = phi1;
+      if (rcc && !c.status) { c.status = rcc; c.err_step = c.step + 1; c.err_layer = 1; }
+    }
     if (LAST) {
       if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
         const double t2 = psi_g * thick * rho_l;
@@ -1667,9 +1720,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
           flux = dmin(flux, psi_l * rho_l * thick);
           S_abs = S_abs - flux * S_br;
           if (S_abs < 0.0 && !stop_layer) stop_layer = j;
-          CL(grav_temp) = CL(grav_temp) + flux * T;
-          H_abs = H_abs - flux * c_l * T;
-          heat_loss = heat_loss + flux * c_l * T;
+          CL(grav_temp) = CL(grav_temp) + flux * Tl;
+          H_abs = H_abs - flux * c_l * Tl;
+          heat_loss = heat_loss + flux * c_l * Tl;
           cum = cum + flux;
           flup = dmin(cum, psi_l * rho_l * thick);
         }
@@ -1704,15 +1757,20 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       flup_pp = prev.flup;
     }
     hr_up = hr; flq_up = flq;
-    prev.T = T; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
+    prev.T = Tl; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
     ST_MARK(ST_D_B);
   };
   const int jmax = wave_max(Na);
   auto request = [&](const int j) { ahead2 = load_ld(j + 2 <= N ? j + 2 : N); };      // top of iteration j: layer j+2
   auto advance = [&](const int j) { raw = finish(ahead, j + 1); ahead = ahead2; };      // end of iteration j: layer j+1 becomes current
   // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
-  if (1 < Na) { request(1); layer(1, ahead, std::false_type{}); advance(1); }
-  if (2 < Na) { request(2); layer(2, ahead, std::false_type{}); advance(2); }
+  if (1 < Na) { request(1); layer(1, ahead, std::false_type{}, std::true_type{}); advance(1); }
+  if (2 < Na) { request(2); layer(2, ahead, std::false_type{}, std::false_type{}); advance(2); }
+  if (late_rad) {   // (see the head of the routine; nothing above reads fl_rad, the albedo or the short-wave flux)
+    const double beer0 = radiation_header<K>(c, x, time, tc);
+    c.frad = 0.0;
+    if (do_beer) sweep_beer<K>(c, x, beer0);
+  }
   // ---- Who reads the psi_s / psi_l / psi_g rows of the layers below?  The vital signs at the next output point and a get_state
   // after the launch (force_psi), and -- when the surface melts or the snow releases melt water -- func_freeboard and flush3
   // (mo_grotz.f90:636,670,717-725).  With N_active >= 3 layer 1 is complete by now (its return-flow transfer C(1) ran with
@@ -1751,17 +1809,17 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       if (j + 1 < Na) {                                  // both layers are interior layers of this column: one straight-line body
         ST_COUNT(CT_DOWN_TRIPS, 2);
         ahead2 = load_ld(j + 2 <= N ? j + 2 : N);        // layer j+2 -> second buffer
-        layer(j, ahead, std::false_type{});
+        layer(j, ahead, std::false_type{}, std::false_type{});
         raw = finish(ahead, j + 1);
         ahead = load_ld(j + 3 <= N ? j + 3 : N);         // layer j+3 -> first buffer
-        layer(j + 1, ahead2, std::false_type{});
+        layer(j + 1, ahead2, std::false_type{}, std::false_type{});
         raw = finish(ahead2, j + 2);
       }
 #ifndef SAMSIM_DUNROLL_NOELSE
       else if (j < Na) {                               // layer j is the column's last interior layer
         ST_COUNT(CT_DOWN_TRIPS, 1);
         ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
-        layer(j, ahead, std::false_type{});
+        layer(j, ahead, std::false_type{}, std::false_type{});
         raw = finish(ahead, j + 1);
       }
 #endif
@@ -1769,7 +1827,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     }
     if (j < jmax && j < Na) {                            // odd number of interior layers in the longest column of the wave
       ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
-      layer(j, ahead, std::false_type{});
+      layer(j, ahead, std::false_type{}, std::false_type{});
       raw = finish(ahead, j + 1);
     }
   }
@@ -1780,12 +1838,12 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     if (j >= Na) continue;
     ST_COUNT(CT_DOWN_TRIPS, 1);
     request(j);
-    layer(j, ahead, std::false_type{});
+    layer(j, ahead, std::false_type{}, std::false_type{});
     advance(j);
     ISA_MARK("D_ITER_END");
   }
 #endif
-  layer(Na, ahead, std::true_type{});                  // the bottom layer (this sweep only runs with N_active >= 2)
+  layer(Na, ahead, std::true_type{}, std::false_type{});                  // the bottom layer (this sweep only runs with N_active >= 2)
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
     prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
@@ -2824,7 +2882,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool coupling = (CL(m_snow) > 0.0 && CL(thick_snow) < g.thick_min);
   const bool flood_possible = (CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                CL(m_snow) > c.buoy_s * (rho_l - rho_s));
-  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && !coupling && !flood_possible &&
+  // (a thin snow cover no longer needs the unfused order: the fused down sweep couples it to the top layer in place, SAMSIM_FUSE_COUPLING)
+  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && (SAMSIM_FUSE_COUPLING || !coupling) && !flood_possible &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2)
 #if SAMSIM_THICK_RULE
@@ -2857,8 +2916,13 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
     testcase_scalars<K>(c, x, g, time);
-    const double beer0 = radiation_header<K>(c, x, time, tc);
-    c.frad = 0.0;
+    // with a thin snow cover somewhere in the wave the radiation header waits for the coupling inside the sweep (it reads T_snow)
+    const bool late_rad = SAMSIM_FUSE_COUPLING && __ballot(coupling) != 0ull;
+    double beer0 = 0.0;
+    if (!late_rad) {
+      beer0 = radiation_header<K>(c, x, time, tc);
+      c.frad = 0.0;
+    }
     // The volume fractions of layers >= 3 are only stored where something reads them (see sweep_down_fused): always through the
     // run-time-flag instantiation; with melt-water flushing (flush_flag 5 on the radiative surface) the sweep decides from the
     // finished top layer; without it (flush_flag 1) only the vital signs at the next output point and a get_state after the
@@ -2870,8 +2934,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 #endif
     // fl_rad(N_active) enters the conductive update of every layer (mo_heat_fluxes.f90:282-285), which the down sweep applies as
     // it goes: the Beer-law product over the layer thicknesses (a pass over one array) comes first
-    if (do_beer) sweep_beer<K>(c, x, beer0);
-    sweep_down_fused<K>(c, x, store_default, decide_psi, surface_done);
+    if (do_beer && !late_rad) sweep_beer<K>(c, x, beer0);
+    sweep_down_fused<K>(c, x, store_default, decide_psi, surface_done, coupling, late_rad, time, tc, do_beer);
     ST_MARK(ST_DFUSED);
     if (c.status) return;
   } else {
