@@ -282,6 +282,10 @@ struct Col {
 #ifndef SAMSIM_FUSE_COUPLING
 #define SAMSIM_FUSE_COUPLING 1
 #endif
+// SAMSIM_RTH_RULE: the fused up sweep takes 1/thick of a regular column's layers from two reciprocals formed once per sweep
+#ifndef SAMSIM_RTH_RULE
+#define SAMSIM_RTH_RULE 1
+#endif
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
@@ -947,10 +951,12 @@ __device__ __forceinline__ void ray_scan_init(RayScan &r) {
 
 // Expulsion, mo_thermo_functions.f90:157-187: volume fractions and expelled brine volume of one layer
 struct Expelled { double psi_s, psi_l, psi_g, V_ex; };
-__device__ __forceinline__ Expelled expulsion(double phi, double thick, double m) {
+// (rth = recip(thick): the fused up sweep forms it once per sweep for the two thicknesses of the grid rule; recip() is a function of
+// its argument alone, so the bits are the same wherever it is formed)
+__device__ __forceinline__ Expelled expulsion(double phi, double thick, double m, double rth) {
   Expelled e;
 #if SAMSIM_FAST_DIV
-  const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l), rth = recip(thick);
+  const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l);
   e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
   e.psi_s = V_s * rth;
   e.psi_l = (V_l - e.V_ex) * rth;
@@ -972,10 +978,10 @@ __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m
 // writes the psi arrays itself, which is cheaper than handing psi_s, psi_l, psi_g and V_ex over through HBM.
 template <class K>
 __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bool do_ray, double T, double phi, double S_bu,
-                                         double m, double thick, RayScan &r, bool sparse_rows = false) {
+                                         double m, double thick, double rth, RayScan &r, bool sparse_rows = false) {
   const samsim_config &g = x.p->cfg;
   const double S_br = S_br_clamped(x.salt, T, S_bu);
-  const Expelled e = expulsion(phi, thick, m);
+  const Expelled e = expulsion(phi, thick, m, rth);
   r.min_psi_s = dmin(r.min_psi_s, e.psi_s);
   r.buoy_s += e.psi_s * thick;
   if (k == 1) c.psi_l_top = e.psi_l;
@@ -1065,7 +1071,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
       // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
       LAYU(SAMSIM_A_T, k) = T;
       LAYU(SAMSIM_A_PHI, k) = phi;
-      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, r);
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r);
     }
   };
   if (check_wave) run(std::true_type{}); else run(std::false_type{});
@@ -1097,7 +1103,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
-  s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, r);
+  s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r);
   c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, 1);
@@ -1139,7 +1145,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     // S_br(k) of the first sweep = func_S_br(T, S_abs/m) with the mass BEFORE expulsion_flux: recomputed bit for bit
     // (same inputs, same operations) instead of being stored by every S1 sweep; this unfused path keeps it for P3
     const double S_br = S_br_clamped(x.salt, T, S_bu_in);
-    const Expelled ex = expulsion(phi_from_T(x.salt, H_in, S_bu_in, S_br), thick, m);
+    const Expelled ex = expulsion(phi_from_T(x.salt, H_in, S_bu_in, S_br), thick, m, recip(thick));
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g;
     double flm_next;
@@ -1590,6 +1596,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
 #if SAMSIM_THICK_RULE
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
+#if SAMSIM_RTH_RULE >= 2
+  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
+#endif
 #endif
   auto load_ld = [&](int j) -> Ld {
     Ld r;
@@ -1641,7 +1650,13 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
     double H_abs = raw.H_abs;
-    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m);
+#if SAMSIM_RTH_RULE >= 2 && SAMSIM_THICK_RULE
+    // (fused path: regular columns only, so 1/thick of layers >= 2 is one of two reciprocals formed once per sweep)
+    const double rth = (j >= 2) ? ((j > g.n_top && j <= g.n_top + g.n_middle) ? rth_mid : rth_0) : recip(thick);
+#else
+    const double rth = recip(thick);
+#endif
+    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, rth);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
@@ -2024,6 +2039,10 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
 #if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
+#if SAMSIM_RTH_RULE
+  // 1/thick of the two thicknesses of the grid rule, once per sweep (an irregular column forms it per layer)
+  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
+#endif
 #endif
   auto load_ul = [&](int j) -> UL {
     UL r;
@@ -2098,7 +2117,12 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, r, true);
+#if SAMSIM_RTH_RULE && SAMSIM_THICK_RULE
+      const double rth_k = regular ? ((k > g.n_top && k <= g.n_top + g.n_middle) ? rth_mid : rth_0) : recip(th_k);   // (k >= 2 here)
+#else
+      const double rth_k = recip(th_k);
+#endif
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, rth_k, r, true);
     }
     ST_MARK(ST_U_TAIL);
   };
