@@ -1596,9 +1596,6 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
 #if SAMSIM_THICK_RULE
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-#if SAMSIM_RTH_RULE >= 2
-  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
-#endif
 #endif
   auto load_ld = [&](int j) -> Ld {
     Ld r;
@@ -1650,13 +1647,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
     double H_abs = raw.H_abs;
-#if SAMSIM_RTH_RULE >= 2 && SAMSIM_THICK_RULE
-    // (fused path: regular columns only, so 1/thick of layers >= 2 is one of two reciprocals formed once per sweep)
-    const double rth = (j >= 2) ? ((j > g.n_top && j <= g.n_top + g.n_middle) ? rth_mid : rth_0) : recip(thick);
-#else
-    const double rth = recip(thick);
-#endif
-    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, rth);
+    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, recip(thick));
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
