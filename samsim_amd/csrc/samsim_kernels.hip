@@ -370,6 +370,25 @@ __device__ __forceinline__ double dmin(double a, double b) {
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 #endif
+// a*b + C and max(a, C) with the constant C read from a scalar register pair.  Left to itself the compiler picks the accumulating
+// form (v_fmac) for a*b + constant and first copies the constant into the accumulator -- two v_mov_b32 per fused multiply-add, and a
+// vector move costs the SIMD the same four cycles as the arithmetic it feeds.  (One scalar operand per instruction is what the
+// encoding allows, so a step with two constants is a multiply and an add.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_c(double a, double b, double c_const) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
+  return r;
+}
+__device__ __forceinline__ double max_c(double a, double c_const) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c_const));
+  return r;
+}
+#else
+__device__ __forceinline__ double fma_c(double a, double b, double c_const) { return __builtin_fma(a, b, c_const); }
+__device__ __forceinline__ double max_c(double a, double c_const) { return a > c_const ? a : c_const; }
+#endif
 // S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594
 __device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
 #if SAMSIM_FAST_DIV
@@ -396,7 +415,11 @@ __device__ __forceinline__ double S_br_poly(const Salt &s, double T) {
 }
 __device__ __forceinline__ double S_br_clamped(const Salt &s, double T, double S_bu) {
   double v = S_br_poly(s, T);
+#if SAMSIM_CLAMP_MAX
+  return dmax(v, S_bu);   // one v_max_f64 for the compare and two 32-bit selects of `v < S_bu ? S_bu : v`: the same number for numbers
+#else
   return v < S_bu ? S_bu : v;
+#endif
 }
 // func_ddT_S_br, mo_thermo_functions.f90:380-414 (derivative-only clamp below -20 C)
 __device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
@@ -431,6 +454,10 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 #ifndef SAMSIM_NEWTON1
 #define SAMSIM_NEWTON1 1
 #endif
+// SAMSIM_CLAMP_MAX: the clamps of the liquidus and of Expulsion as single v_max_f64
+#ifndef SAMSIM_CLAMP_MAX
+#define SAMSIM_CLAMP_MAX 0
+#endif
 #ifndef SAMSIM_NEWTON_FMA
 #define SAMSIM_NEWTON_FMA 1
 #endif
@@ -440,6 +467,22 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
   // the same step with fused multiply-adds (one rounding per a*b+c instead of two: 27 vector instructions instead of 41 per
   // evaluation, 3.6 evaluations per layer-cell, all on the critical path of the up sweep); each iterate within an ulp or two
   // of the unfused form's, like the other ulp-level changes of this file
+#if SAMSIM_NEWTON_FMA == 2
+  // (the constants as scalar operands: fma_c above; 28 vector instructions per evaluation where the compiler's choice of
+  // accumulating multiply-adds took 35)
+  const double sbf = T_0 * fma_c(T_0, T_0 * s.c4 + s.c3, s.c2);
+  if (sbf > 0.0001) {
+    const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
+    const double A = __builtin_fma(T_0, T_0 * (0.5 * c_s_beta) + c_s, -latent_heat - H);
+    const double B = c_s_beta * T_0 + c_s;
+    const double num = __builtin_fma(A, sb2, LS * sbf);
+    const double Tc = max_c(T_0, -20.0);
+    const double dd = fma_c(Tc, Tc * (3.0 * s.d4) + 2.0 * s.d3, s.d2);
+    const double den = __builtin_fma(B, sb2, -(LS * dd));
+    T_new = T_0 - quot(num, den);
+    return fabs(num) > sb2;
+  }
+#else
   const double sbf = T_0 * __builtin_fma(T_0, __builtin_fma(T_0, s.c4, s.c3), s.c2);
   if (sbf > 0.0001) {
     const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
@@ -452,6 +495,7 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
     T_new = T_0 - quot(num, den);
     return fabs(num) > sb2;
   }
+#endif
 #endif
   const double sb = S_br_poly(s, T_0);
 #if SAMSIM_NEWTON1 && SAMSIM_FAST_DIV
@@ -957,7 +1001,11 @@ __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m
   Expelled e;
 #if SAMSIM_FAST_DIV
   const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l);
+#if SAMSIM_CLAMP_MAX
+  e.V_ex = dmax(V_l + V_s - thick, 0.0);   // (a sum above thick leaves a positive difference, one at or below it none)
+#else
   e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
+#endif
   e.psi_s = V_s * rth;
   e.psi_l = (V_l - e.V_ex) * rth;
   e.psi_g = (thick - V_l - V_s + e.V_ex) * rth;
@@ -968,8 +1016,13 @@ __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m
   e.psi_l = (V_l - e.V_ex) / thick;
   e.psi_g = (thick - V_l - V_s + e.V_ex) / thick;
 #endif
+#if SAMSIM_CLAMP_MAX
+  e.psi_l = dmax(e.psi_l, 0.0);
+  e.psi_g = dmax(e.psi_g, 0.0);
+#else
   if (e.psi_l < 0.0) e.psi_l = 0.0;
   if (e.psi_g < 0.0) e.psi_g = 0.0;
+#endif
   return e;
 }
 
