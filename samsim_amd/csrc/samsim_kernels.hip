@@ -456,7 +456,7 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 #endif
 // SAMSIM_CLAMP_MAX: the clamps of the liquidus and of Expulsion as single v_max_f64
 #ifndef SAMSIM_CLAMP_MAX
-#define SAMSIM_CLAMP_MAX 0
+#define SAMSIM_CLAMP_MAX 1
 #endif
 #ifndef SAMSIM_NEWTON_FMA
 #define SAMSIM_NEWTON_FMA 1
