@@ -193,16 +193,20 @@ def test_flood_simple_under_heavy_snow():
     assert so.sc("thick_snow").max() < snow0 - 0.05, "flood_simple did not fire"
 
 
-def test_grid_of_columns_on_four_forcing_sites():
-    """samsim_set_forcing_sites: 64 perturbed columns spread over the SHEBA, North Pole, Barrow and 70N00W
-    tables; free run from open water through freeze-up against the oracle (every column reads its own tables), and the
-    snapshots of an unperturbed North Pole column against the reference's own run on those tables"""
+def test_grid_of_columns_on_all_nine_forcing_sites():
+    """samsim_set_forcing_sites: 72 perturbed columns spread over the nine ERA-interim sites of the reference
+    (SHEBA, North Pole, Barrow, 70N00W, 75N180E, 80N00E, 75N00W, 85N180E, 80N90E); free run from open water through freeze-up
+    against the oracle (every column reads its own tables), and the snapshots of an unperturbed North Pole column against the
+    reference's own run on those tables"""
     sites = ["NorthPole", "barrow", "70N00W"]
-    z = golden("era_sites_forcing.npz")
+    more = ["75N180E", "80N00E", "75N00W", "85N180E", "80N90E"]
+    z, zm = golden("era_sites_forcing.npz"), golden("era_sites_forcing_more.npz")
     sheba = sheba_forcing()
-    tables = [np.stack([sheba[i]] + [z[f"{s}_{n}"] for s in sites]) for i, n in enumerate(("fl_sw", "fl_lw", "T2m", "precip"))]
-    ncol = 64
-    site = (np.arange(ncol) % 4).astype(np.int32)
+    tables = [np.stack([sheba[i]] + [z[f"{s}_{n}"] for s in sites] + [zm[f"{s}_{n}"] for s in more])
+              for i, n in enumerate(("fl_sw", "fl_lw", "T2m", "precip"))]
+    nsite = 1 + len(sites) + len(more)
+    ncol = 8 * nsite
+    site = (np.arange(ncol) % nsite).astype(np.int32)
     dT, ps = tcs.ensemble_perturbation(ncol)
     dT[1], ps[1] = 0.0, 1.0                               # column 1 = the North Pole member as the reference runs it
     cfg, st = tcs.testcase4(ncol)
@@ -220,12 +224,12 @@ def test_grid_of_columns_on_four_forcing_sites():
         for n, floor in (("T2m", 1e-2), ("T_top", 1e-2), ("thickness", 1e-7), ("thick_snow", 1e-7), ("bulk_salin", 1e-5)):
             assert rel_err(out.sc(n)[0], ref["all_s_" + n][i], floor) <= RTOL, f"north pole output {i}: {n}"
     o.step(g.get_clock().step)
-    sg, so = _check(g, o, "four sites, day 5")
+    sg, so = _check(g, o, "nine sites, day 5")
     g.step(30000)
     o.step(30000)
-    sg, so = _check(g, o, "four sites, +30000")
+    sg, so = _check(g, o, "nine sites, +30000")
     T2m = so.sc("T2m")
-    assert len({round(float(T2m[site == k].mean()), 3) for k in range(4)}) == 4      # the four sites really differ
+    assert len({round(float(T2m[site == k].mean()), 3) for k in range(nsite)}) == nsite      # the sites really differ
 
 
 VARIANTS = {"prescribe": dict(flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2), "flush6": dict(flush_flag=6)}

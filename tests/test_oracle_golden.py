@@ -343,6 +343,35 @@ def test_tc4_on_north_pole_forcing_bitwise():
     assert not o.get_status()[0].any()
 
 
+class _Prefixed:
+    """view of a fixture whose keys carry a site prefix"""
+    def __init__(self, z, prefix):
+        self.z, self.p = z, prefix
+
+    def __getitem__(self, k):
+        return self.z[self.p + k]
+
+
+@pytest.mark.parametrize("site", ["75N180E", "80N00E", "75N00W", "85N180E", "80N90E"])
+def test_tc4_on_the_other_era_interim_sites_bitwise(site):
+    """the five remaining ERA-interim sites of the reference (input/ERA-interim/<site>-p2): testcase 4 on their
+    tables, first 150 output days (open water, freeze-up, growth to 60-100 layers) against the flang-built reference run in a
+    directory that holds those tables (tests/golden/make_site_fixtures.py), bit for bit"""
+    cfg, st = tcs.testcase4(1)
+    z = golden("era_sites_forcing_more.npz")
+    o = oracle_solver(cfg, 1)
+    o.set_forcing(*[z[f"{site}_{n}"] for n in ("fl_sw", "fl_lw", "T2m", "precip")])
+    o.set_state(st)
+    o.set_clock()
+    ref = _Prefixed(golden("tc4_sites_ref.npz"), site + "_")
+    rows = {int(x): j for j, x in enumerate(ref["index"])}
+    n = len(ref["all_step"])
+    assert n == 150 and ref["all_N_active"][-1] > 50
+    for i in range(n):
+        _compare_output(o.run_to_output(), ref, i, rows.get(i), f"{site} day {i + 1}", layers=LAYERS)
+    assert not o.get_status()[0].any()
+
+
 def bgc_bu_br(bgc_abs, bgc_bottom, m, psi_l, thick, na):
     """output_bgc, mo_output.f90:156-188: the bulk and brine concentrations the reference prints per tracer"""
     nb, nl = bgc_abs.shape
