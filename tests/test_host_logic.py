@@ -145,3 +145,41 @@ def test_ensemble_statistics_of_the_checker():
         assert abs(q.mean - v.mean()) <= 1e-13 * max(1.0, abs(v.mean())) and abs(q.std - v.std()) <= 1e-12 * max(1.0, v.std())
     assert stats["N_active"].max == s.n_active.max() and stats["N_active"].mean == pytest.approx(s.n_active.mean())
     assert stats["T2m"].std > 0.5
+
+
+def test_device_layout_index_is_a_bijection(tmp_path):
+    """samsim_device.h: the layer block is stored per 64-column block, [block][layer][array][lane].  DEV_LAY_INDEX must map every
+    (array, layer, column) of a handle to its own double inside DEV_LAY_DOUBLES, keep a wave's 64 columns of one (array, layer)
+    contiguous, and keep the sixteen arrays of a layer row within 8 KiB of each other (the kernel addresses them with the
+    signed 13-bit immediate of one row address) -- checked on the host with the header compiled by g++."""
+    import os
+    import subprocess
+    from tests.helpers import ROOT
+    src = tmp_path / "layout.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <vector>
+#include "samsim_device.h"
+int main() {
+  const int N = 7; const size_t ncol = 200;   // not a multiple of 64: the last block is ragged
+  const size_t total = DEV_LAY_DOUBLES(N, ncol);
+  std::vector<char> seen(total, 0);
+  for (int a = 0; a < DEV_NARR; ++a) for (int k = 0; k < N; ++k) for (size_t c = 0; c < ncol; ++c) {
+    const size_t i = DEV_LAY_INDEX(a, k, c, N, ncol);
+    if (i >= total || seen[i]) { std::printf("clash a=%d k=%d c=%zu\n", a, k, c); return 1; }
+    seen[i] = 1;
+  }
+  // lanes contiguous, arrays of a row 512 B apart, rows DEV_ROWB apart
+  if (DEV_LAY_INDEX(3, 2, 65, N, ncol) != DEV_LAY_INDEX(3, 2, 64, N, ncol) + 1) return 2;
+  if ((DEV_LAY_INDEX(4, 2, 64, N, ncol) - DEV_LAY_INDEX(3, 2, 64, N, ncol)) * 8 != 512) return 3;
+  if ((DEV_LAY_INDEX(0, 3, 64, N, ncol) - DEV_LAY_INDEX(0, 2, 64, N, ncol)) * 8 != DEV_ROWB) return 4;
+  if (DEV_ROWB != 8192 || DEV_NARR != 16) return 5;
+  std::printf("ok %zu\n", total);
+  return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    inc = os.path.join(ROOT, "samsim_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout
