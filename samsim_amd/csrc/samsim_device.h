@@ -1,8 +1,9 @@
 // samsim_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
 //
 // HBM layout (one allocation per handle, sized for ncol columns of nlayer layers):
-//   lay  [DEV_NARR][nlayer][ncol] float64   layer arrays, column fastest: a wave's 64 lanes read 512
-//                                           contiguous bytes for every (array, layer) pair
+//   lay  [ncol/64][nlayer][DEV_NARR][64] float64   layer arrays per 64-column block (SAMSIM_BLOCKED below): a wave's 64
+//                                           lanes read 512 contiguous bytes for every (array, layer) pair, the sixteen arrays of
+//                                           a layer row are 8 KiB, a wave's whole block is one contiguous piece
 //   scal [SAMSIM_NSCAL][ncol]     float64   per-column scalars
 //   n_active/status/err_layer [ncol] int32, err_step/work [ncol] int64
 // One GPU thread owns one column for the whole launch; a launch advances every column `nsteps` time steps.

@@ -2,10 +2,12 @@
 //
 // What it computes: the body of the reference time loop, pgriewank/SAMSIM mo_grotz.f90:182-835, for `ncol`
 // independent columns, `nsteps` steps per launch.  One lane owns one column for the whole launch (columns
-// never communicate), state lives in HBM as [array][layer][column] float64 so that every per-layer access of
-// a wave is one contiguous 512-byte line, and a column's layers are walked sequentially inside the lane with
-// the neighbour values (k-1, k, k+1) carried in registers.  No MFMA (there is no contraction in this path),
-// no LDS (the stencil neighbours are register-carried), no cross-lane traffic.
+// never communicate), state lives in HBM per 64-column block as [block][layer][array][lane] float64 so that every
+// per-layer access of a wave is one contiguous 512-byte line and a layer row's arrays sit within one row address's
+// immediate range, and a column's layers are walked sequentially inside the lane with the neighbour values
+// (k-1, k, k+1) carried in registers.  No MFMA (there is no contraction in this path); LDS holds the per-column
+// scalars that must survive the two layer loops of a step (19 slots per lane, own words only: no barrier); no
+// cross-lane traffic except wave-uniform votes.
 //
 // The sequential structure inside a column is dictated by the reference: getT's Newton iteration is seeded
 // with the temperature of the layer below (mo_grotz.f90:298-303) and stops at |f| <= 1 J/kg, so the result
@@ -199,7 +201,7 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 };
 
 struct Col {
-  gdouble *lay;  // UNIFORM base of the [array][layer][column] block (same in every lane)
+  gdouble *lay;  // UNIFORM: 4096 bytes into the wave's 64-column block of the layer arrays (SAMSIM_BLOCKED; else the block's base)
   unsigned col; // this lane's column
   unsigned coff;     // col * 8: byte offset of the column inside a row of the scalar / hand-over blocks
   unsigned lcoff;    // lane * 8: byte offset of the column inside a row of its 64-column block (SAMSIM_BLOCKED)
