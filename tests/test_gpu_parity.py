@@ -141,23 +141,26 @@ def test_sheba_melt_season_one_day():
 
 
 def test_launch_granularity_does_not_change_results():
-    """1000 steps in one launch == 10 launches of 100 == 1000 launches of 1 (bitwise): the uniform clock carried by the
-    host and the state carried in HBM are the whole state"""
+    """1000 steps in one launch == 10 launches of 100 == 143 launches of 7 == samsim_steps_timed(50, 20) (bitwise): the uniform
+    clock carried by the host and the state carried in HBM are the whole state"""
     st1, clock = load_checkpoint("tc4_spunup_state.npz")
     cfg, _ = tcs.testcase4(1)
     ncol = 128
     res = []
-    for chunk in (1000, 100, 7):
+    for chunk in (1000, 100, 7, -50):
         g = samsim_amd.hip_solver(cfg, ncol)
         dT, ps = tcs.ensemble_perturbation(ncol)
         g.set_forcing(*sheba_forcing(), dT, ps)
         g.set_state(st1.replicate(ncol))
         g.set_clock(**clock)
-        done = 0
-        while done < 1000:
-            n = min(chunk, 1000 - done)
-            g.step(n)
-            done += n
+        if chunk < 0:      # samsim_steps_timed: 20 launches of 50 steps enqueued back to back and timed as one region
+            assert g.steps_timed(-chunk, 1000 // -chunk) > 0.0
+        else:
+            done = 0
+            while done < 1000:
+                n = min(chunk, 1000 - done)
+                g.step(n)
+                done += n
         res.append((g.get_state(), g.get_clock()))
         g.close()
     for st, clk in res[1:]:
