@@ -189,6 +189,14 @@ MODULE mo_samsim_capi
        IMPORT
        TYPE(c_ptr), VALUE :: h
      END FUNCTION
+     !> nlaunches launches of nsteps steps, enqueued back to back, and the device time of the sequence [ms] (ABI 4)
+     INTEGER(c_int) FUNCTION samsim_steps_timed(h, nsteps, nlaunches, device_ms) BIND(C, name='samsim_steps_timed')
+       IMPORT
+       TYPE(c_ptr), VALUE :: h
+       INTEGER(c_int64_t), VALUE :: nsteps
+       INTEGER(c_int32_t), VALUE :: nlaunches
+       REAL(c_double), INTENT(out) :: device_ms
+     END FUNCTION
      SUBROUTINE samsim_destroy(h) BIND(C, name='samsim_destroy')
        IMPORT
        TYPE(c_ptr), VALUE :: h
