@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fill the @MARKER@ fields of DESIGN.md from the committed summaries under profiles/ (run after tools/collect_profiles.py)."""
+"""Fill the @MARKER@ fields of DESIGN.md (the table and the paragraph of section 4 carry them while a round is in progress) from the
+committed summaries under profiles/; run after tools/collect_profiles.py.  Once filled, the markers are gone: put them back to refill."""
 import json
 import re
 import sys
@@ -22,8 +23,7 @@ v = {
     "VBUSY": "%.0f" % (100 * pm["valu_busy_frac"]),
     "TBS": "%.1f" % (pm["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12),
 }
-s = open("DESIGN.md").read()
-tmpl = open("DESIGN.md.in").read() if False else s
+tmpl = open("DESIGN.md").read()
 for k, x in v.items():
     tmpl = tmpl.replace("@%s@" % k, x)
 left = re.findall(r"@[A-Z0-9]+@", tmpl)
