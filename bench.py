@@ -301,7 +301,18 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on the C-level stdout; stdout is for the ONE JSON line, so fd 1 points at stderr while
+        # the ranks connect (init + a first barrier, which is when the full mesh is made)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if args.dry_run:
         # the launch plumbing alone: every rank reports its shard, rank 0 prints what a real run would call n_gpus
