@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAMSIM_ABI_VERSION 4
+#define SAMSIM_ABI_VERSION 5
 #define SAMSIM_MAX_NLAYER 1024
 
 /* -------- configuration: every flag of mo_data.f90:136-155 plus the scalars mo_init sets -------- */
@@ -138,8 +138,10 @@ typedef struct samsim_handle samsim_handle;
 
 /* sub_allocate (mo_init.f90:2040-2090) + the flag/scalar part of init (mo_init.f90:83-132, 1981-2031).
  * device: HIP device ordinal.  ncol columns of nlayer layers are allocated on it.  One handle holds at most
- * nlayer * ncol < 2^29 layer cells (4 GiB per layer array: SAMSIM_ERR_ARG beyond); larger ensembles take several
- * handles (column ranges), which is also how they are spread over GPUs. */
+ * SAMSIM_MAX_NCOL columns (its [SAMSIM_NSCAL][ncol] scalar block is addressed with 32-bit byte offsets: SAMSIM_ERR_ARG
+ * beyond), whatever nlayer is; larger ensembles take several handles (column ranges), which is also how they are spread
+ * over GPUs. */
+#define SAMSIM_MAX_NCOL ((int64_t)(((1ull << 32) - 1) / (8ull * SAMSIM_NSCAL)))
 int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim_handle **h);
 
 /* sub_input (mo_functions.f90:304-327): 3-hourly tables, time_input(k) = (k-1)*10800 s.
@@ -180,6 +182,11 @@ int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms);
  * head of the next), and the device time of the whole sequence, measured with HIP events on the handle's streams (ABI 4) */
 int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, double *device_ms);
 int samsim_synchronize(samsim_handle *h);
+/* How a step of a large ensemble is launched (no reference counterpart; results do not depend on it, bit for bit).  From
+ * min_blocks 64-column blocks up (default 8 192 = 524 288 columns; 0 = never) a step runs as two concurrent launches on the
+ * handle's two HIP streams, the first taking first_part_eighths/8 of the blocks (default 4): the workgroups of one launch finish
+ * raggedly and a second launch in flight tops the chip up.  Every other entry point waits for both.  ABI 5. */
+int samsim_set_launch_split(samsim_handle *h, int64_t min_blocks, int32_t first_part_eighths);
 
 /* number of steps until (and including) the next output point of mo_grotz.f90:340 */
 int64_t samsim_steps_to_output(samsim_handle *h);
@@ -187,8 +194,8 @@ int samsim_set_output_window(samsim_handle *h, int64_t col0, int64_t ncols);
 /* output (mo_output.f90:116-146): latest snapshot; returns SAMSIM_ERR_NO_OUTPUT if none was taken */
 int samsim_get_output(samsim_handle *h, samsim_output_soa *o);
 
-/* the reference's STOP codes: status[c] = 0 or code; step/layer of first failure.
- * 9001 is the library's own: an internal hand-over assumption of the fused sweeps did not hold for this column. */
+/* the reference's STOP codes: status[c] = 0 or code; step/layer of first failure.  Every code is one of the
+ * reference's own (16, 99, 345, 431, 1337, 7889, 9876, 21234, ...): the library stops no column the reference would not. */
 int samsim_get_status(samsim_handle *h, int32_t *status, int64_t *step, int32_t *layer);
 /* restart only: puts back what samsim_get_status returned for the columns [col0, col0+ncols) (samsim_set_state clears the
  * status of the columns it uploads), so that a column frozen by a STOP code stays frozen -- and reported -- after a

@@ -31,5 +31,10 @@ def load() -> _C.CDLL:
 
 
 def hip_solver(cfg: Config, ncol: int, device: int = 0) -> Solver:
-    """samsim_create on `device`"""
-    return Solver(load(), "samsim_", cfg, ncol, device)
+    """samsim_create on `device`.  SAMSIM_TEST_SPLIT_BLOCKS (read HERE, by the Python mirror -- the library reads no environment)
+    lowers the block count from which a step runs as two concurrent launches: the whole GPU suite can be run with every launch
+    split (samsim_set_launch_split)."""
+    s = Solver(load(), "samsim_", cfg, ncol, device)
+    if "SAMSIM_TEST_SPLIT_BLOCKS" in _os.environ:
+        s.set_launch_split(int(_os.environ["SAMSIM_TEST_SPLIT_BLOCKS"]), 4)
+    return s

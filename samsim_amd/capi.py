@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _CFG_INT_FIELDS = [
     "struct_size", "testcase", "nlayer", "n_top", "n_middle", "n_bottom",
@@ -214,6 +214,8 @@ class Solver:
         f.argtypes, f.restype = [vp, i64, C.c_int32, C.POINTER(C.c_double)], C.c_int
         f = self._f("synchronize")
         f.argtypes, f.restype = [vp], C.c_int
+        f = self._f("set_launch_split")
+        f.argtypes, f.restype = [vp, i64, C.c_int32], C.c_int
 
     # -- API
     def set_forcing(self, fl_sw, fl_lw, T2m, precip, dT2m=None, precip_scale=None):
@@ -286,6 +288,10 @@ class Solver:
 
     def synchronize(self):
         self._chk(self._f("synchronize")(self._h), "synchronize")
+
+    def set_launch_split(self, min_blocks: int = 8192, first_part_eighths: int = 4):
+        """from how many 64-column blocks a step runs as two concurrent launches (0 = never), and the first part's share"""
+        self._chk(self._f("set_launch_split")(self._h, min_blocks, first_part_eighths), "set_launch_split")
 
     def steps_to_output(self) -> int:
         return int(self._f("steps_to_output")(self._h))

@@ -21,7 +21,6 @@ extern "C" hipError_t samsim_launch_step(const DevParams *d_params, const DevPar
 namespace {
 
 constexpr int kRing = 16;
-constexpr int kMaxParts = 4;
 
 thread_local char g_last_hip_error[256] = "";
 
@@ -47,14 +46,11 @@ struct samsim_handle {
   // four rounds of a 16 384-block launch leaves the chip partly idle for 15 % of a workgroup's run time), and with two launches
   // in flight per step, and the next step's enqueued behind them, a draining launch is topped up by the others.  Every other entry point waits for both.
   hipStream_t stream2 = nullptr;
-  hipStream_t streamx[kMaxParts - 2]{};   // further streams when SAMSIM_SPLIT_PARTS asks for more than two parts (tuning runs)
-  hipEvent_t ev1x[kMaxParts - 2]{};
-  int split_parts = 2;
   hipEvent_t fork = nullptr;      // recorded on `stream` when other work was enqueued there since the last launch: stream2 waits for it
   bool other_work = true;
-  int split_eighths = 4;          // share of the first part in eighths (SAMSIM_SPLIT_EIGHTHS overrides: tuning runs; 4, 5, 6, 7 eighths
-                                  // measured 962, 973, 968, 992 ms per 500-step step of 1 048 576 columns, one launch 1 009 ms)
-  long long split_blocks = 8192;  // a launch of at least this many 64-column blocks is split (SAMSIM_SPLIT_BLOCKS overrides: tests, 0 = never)
+  int split_eighths = 4;          // share of the first part in eighths (samsim_set_launch_split; 4, 5, 6, 7 eighths measured 962, 973,
+                                  // 968, 992 ms per 500-step step of 1 048 576 columns, one launch 1 009 ms; three and four parts 1 015, 969-986)
+  long long split_blocks = 8192;  // a launch of at least this many 64-column blocks is split (samsim_set_launch_split; 0 = never)
   hipEvent_t ev0b = nullptr, ev1b = nullptr;
   // device memory
   double *lay = nullptr, *scal = nullptr;
@@ -238,19 +234,18 @@ int launch(samsim_handle *h, long long nsteps) {
   if (h->cfg.bgc_flag == 2 && h->n_bgc < 1) return SAMSIM_ERR_ARG;   // samsim_set_tracers first
   const long long nblk = (h->ncol + 63) / 64;
   // two parts from 8 192 blocks up (two rounds of the chip's 4 096 wave slots): below that a launch has no rounds to speak of
-  const bool split = h->stream2 && h->split_blocks > 0 && nblk >= h->split_blocks && nblk >= h->split_parts;
-  const int nparts = split ? h->split_parts : 1;
-  auto stream_of = [&](int part) { return part == 0 ? h->stream : part == 1 ? h->stream2 : h->streamx[part - 2]; };
-  // part boundaries: the first part takes split_eighths/8 of the blocks when there are two, equal shares otherwise
+  const bool split = h->stream2 && h->split_blocks > 0 && nblk >= h->split_blocks && nblk >= 2;
+  const int nparts = split ? 2 : 1;
+  auto stream_of = [&](int part) { return part == 0 ? h->stream : h->stream2; };
+  // part boundaries: the first part takes split_eighths/8 of the blocks
   auto bound = [&](int part) -> long long {
     if (part <= 0) return 0;
     if (part >= nparts) return nblk;
-    if (nparts == 2) return (nblk * h->split_eighths + 7) / 8;
-    return (nblk * part) / nparts;
+    return (nblk * h->split_eighths + 7) / 8;
   };
   if (split && h->other_work) {
     HIPCHK(hipEventRecord(h->fork, h->stream));
-    for (int part = 1; part < nparts; ++part) HIPCHK(hipStreamWaitEvent(stream_of(part), h->fork, 0));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->fork, 0));
   }
   h->other_work = false;
   for (int part = 0; part < nparts; ++part) {
@@ -293,7 +288,6 @@ int use(samsim_handle *h, bool stepping = false) {
   HIPCHK(hipSetDevice(h->device));
   if (!stepping) {
     if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
-    for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) HIPCHK(hipStreamSynchronize(h->streamx[i]));
     h->other_work = true;
   }
   return SAMSIM_OK;
@@ -329,15 +323,17 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   if (!cfg || !out || ncol <= 0) return SAMSIM_ERR_ARG;
   int rc = validate(*cfg);
   if (rc) return rc;
-  // the kernel addresses a layer array with a 32-bit byte offset (scalar base + one offset register per row)
-  if ((unsigned long long)cfg->nlayer * (unsigned long long)ncol * 8ull >= (1ull << 32)) return SAMSIM_ERR_ARG;
+  // The kernel reaches the [slot][ncol] blocks (per-column scalars, hand-over block of the up sweep) with a scalar base and a 32-bit
+  // byte offset slot * ncol * 8 + col * 8 (GSI / SPEC in samsim_kernels.hip): the widest of them must stay below 4 GiB.  The layer
+  // block has no such bound: it is stored per 64-column block, whose base is 64-bit arithmetic and whose rows (nlayer * 8 KiB) lie
+  // within a 32-bit offset for any nlayer samsim_config admits.
+  constexpr unsigned long long kRows = (int)SAMSIM_NSCAL > (int)DEV_NSPEC ? (int)SAMSIM_NSCAL : (int)DEV_NSPEC;
+  if (kRows * (unsigned long long)ncol * 8ull >= (1ull << 32)) return SAMSIM_ERR_ARG;
   if (device < 0 || device >= samsim_device_count()) return SAMSIM_ERR_NO_DEVICE;
   HIPCHK(hipSetDevice(device));
   samsim_handle *h = new (std::nothrow) samsim_handle();
   if (!h) return SAMSIM_ERR_NOMEM;
   h->cfg = *cfg; h->ncol = ncol; h->device = device;
-  if (const char *e = std::getenv("SAMSIM_SPLIT_BLOCKS")) h->split_blocks = std::atoll(e);
-  if (const char *e = std::getenv("SAMSIM_SPLIT_EIGHTHS")) { const int v = std::atoi(e); if (v >= 1 && v <= 7) h->split_eighths = v; }
   h->clk = samsim_clock{0.0, 0, 0, 1, 0};
   h->p17 = std::pow(10.0, -17.0);
   h->p14 = std::pow(10.0, -14.0);
@@ -347,9 +343,6 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
   ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking), "hipStreamCreate");
   ok = ok && hip_ok(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate");
   ok = ok && hip_ok(hipEventCreate(&h->ev0b), "hipEventCreate") && hip_ok(hipEventCreate(&h->ev1b), "hipEventCreate");
-  if (const char *e = std::getenv("SAMSIM_SPLIT_PARTS")) { const int v = std::atoi(e); if (v >= 2 && v <= kMaxParts) h->split_parts = v; }
-  for (int i = 0; ok && i < h->split_parts - 2; ++i)
-    ok = hip_ok(hipStreamCreateWithFlags(&h->streamx[i], hipStreamNonBlocking), "hipStreamCreate") && hip_ok(hipEventCreate(&h->ev1x[i]), "hipEventCreate");
   ok = ok && hip_ok(dalloc(&h->lay, DEV_LAY_DOUBLES(N, nc)), "hipMalloc lay");
   ok = ok && hip_ok(dalloc(&h->scal, (size_t)SAMSIM_NSCAL * nc), "hipMalloc scal");
   ok = ok && hip_ok(dalloc(&h->n_active, nc), "hipMalloc n_active");
@@ -399,7 +392,6 @@ int samsim_create(const samsim_config *cfg, int64_t ncol, int32_t device, samsim
 void samsim_destroy(samsim_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) (void)hipStreamSynchronize(h->streamx[i]);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
@@ -417,7 +409,6 @@ void samsim_destroy(samsim_handle *h) {
   if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->ev0b) (void)hipEventDestroy(h->ev0b);
   if (h->ev1b) (void)hipEventDestroy(h->ev1b);
-  for (int i = 0; i < kMaxParts - 2; ++i) { if (h->ev1x[i]) (void)hipEventDestroy(h->ev1x[i]); if (h->streamx[i]) (void)hipStreamDestroy(h->streamx[i]); }
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -589,24 +580,26 @@ int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, doub
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventRecord(h->ev1b, h->stream2));
-  for (int i = 0; i < kMaxParts - 2; ++i) if (h->streamx[i]) HIPCHK(hipEventRecord(h->ev1x[i], h->streamx[i]));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventSynchronize(h->ev1b));
   float ms = 0.f, msb = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1b));   // (the other streams' first launches are ordered behind ev0 by the fork event)
   if (msb > ms) ms = msb;
-  for (int i = 0; i < kMaxParts - 2; ++i) {
-    if (!h->streamx[i]) continue;
-    HIPCHK(hipEventSynchronize(h->ev1x[i]));
-    HIPCHK(hipEventElapsedTime(&msb, h->ev0, h->ev1x[i]));
-    if (msb > ms) ms = msb;
-  }
   *device_ms = (double)ms;
   return SAMSIM_OK;
 }
 
 int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms) { return samsim_steps_timed(h, nsteps, 1, kernel_ms); }
+
+int samsim_set_launch_split(samsim_handle *h, int64_t min_blocks, int32_t first_part_eighths) {
+  int rc = use(h);
+  if (rc) return rc;
+  if (min_blocks < 0 || first_part_eighths < 1 || first_part_eighths > 7) return SAMSIM_ERR_ARG;
+  h->split_blocks = min_blocks;
+  h->split_eighths = first_part_eighths;
+  return SAMSIM_OK;
+}
 
 int samsim_synchronize(samsim_handle *h) {
   int rc = use(h);

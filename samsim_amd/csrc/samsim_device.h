@@ -24,20 +24,12 @@ enum dev_layer_array {
 // column block is one contiguous piece (DEV_NARR * 512 B per layer): every array of a layer row sits within the immediate offset
 // range of one row address, a row address is scalar arithmetic, and the lane's offset is the same register for the whole launch.
 // 0 = [array][layer][column].  The boundary (samsim_set_state / samsim_get_state) keeps [array][layer][column] either way.
-#ifndef SAMSIM_BLOCKED
-#define SAMSIM_BLOCKED 1
-#endif
 #define DEV_NARR_C 16                                  // = DEV_NARR
 static_assert(DEV_NARR == DEV_NARR_C, "DEV_NARR_C");
 #define DEV_ROWB ((size_t)DEV_NARR_C * 512)            // bytes of one layer of one 64-column block
 // doubles in the layer block of a handle, and the position of element (array a, 0-based layer k0, column col)
-#if SAMSIM_BLOCKED
 #define DEV_LAY_DOUBLES(N, ncol) ((((size_t)(ncol) + 63) / 64) * (size_t)(N) * DEV_NARR_C * 64)
 #define DEV_LAY_INDEX(a, k0, col, N, ncol) ((((size_t)(col) >> 6) * (size_t)(N) + (size_t)(k0)) * (DEV_NARR_C * 64) + (size_t)(a) * 64 + ((size_t)(col) & 63))
-#else
-#define DEV_LAY_DOUBLES(N, ncol) ((size_t)DEV_NARR_C * (size_t)(N) * (size_t)(ncol))
-#define DEV_LAY_INDEX(a, k0, col, N, ncol) (((size_t)(a) * (size_t)(N) + (size_t)(k0)) * (size_t)(ncol) + (size_t)(col))
-#endif
 
 // per-column values handed from the up sweep of step n to the top-layer prologue of step n+1: [DEV_NSPEC][ncol]
 enum dev_spec {

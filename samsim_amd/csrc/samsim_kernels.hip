@@ -41,10 +41,10 @@
 #define ISA_MARK(name) ((void)0)
 #endif
 #if SAMSIM_STAMPS
-__device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_stamps[48];
 extern "C" int samsim_debug_stamps(unsigned long long *out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 48) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #endif
@@ -55,9 +55,10 @@ namespace {
 enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_TAIL,
        CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
        CT_DRAIN_LANE, CT_DIRTY, CT_L_COUPLING, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B,
-       CT_L_FLOODP = 25, CT_L_IRREG, CT_L_DIRTY, CT_L_UNFUSED, CT_L_FLUSH3, CT_L_REGRID, CT_L_FREEBOARD };
+       CT_L_FLOODP = 25, CT_L_IRREG, CT_L_DIRTY, CT_L_UNFUSED, CT_L_FLUSH3, CT_L_REGRID, CT_L_FREEBOARD,
+       CT_REFILL = 32, ST_NSLOT = 48 };
 struct Stamps {
-  unsigned long long *acc;   // [32] in LDS, one block = one wave
+  unsigned long long *acc;   // [48] in LDS, one block = one wave
   unsigned long long t0;
 };
 __device__ __forceinline__ bool st_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
@@ -160,24 +161,12 @@ bool flags_match(const samsim_config &g) {
 // Device data pointers carry the global address space in their type: an access through them is a global_load / global_store
 // even where the pointer itself has been through memory (a struct passed to a non-inlined function), where the compiler
 // would otherwise have to assume a generic (flat) address.
-#ifndef SAMSIM_AS1
-#define SAMSIM_AS1 1
-#endif
-#if SAMSIM_AS1
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) const double gcdouble;
 typedef __attribute__((address_space(1))) int32_t gint32;
 typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(3))) double ldouble;
 typedef __attribute__((address_space(3))) unsigned long long lu64;
-#else
-typedef double gdouble;
-typedef const double gcdouble;
-typedef int32_t gint32;
-typedef char gchar;
-typedef double ldouble;
-typedef unsigned long long lu64;
-#endif
 // LDS-resident per-column scalars: slot s of lane l is word s*SAMSIM_BLOCK + l of the block's array
 enum lds_slot {
   LD_grav_drain = 0, LD_grav_salt, LD_grav_temp,
@@ -201,10 +190,10 @@ struct Salt {  // liquidus polynomial (func_S_br) and its derivative (func_ddT_S
 };
 
 struct Col {
-  gdouble *lay;  // UNIFORM: 4096 bytes into the wave's 64-column block of the layer arrays (SAMSIM_BLOCKED; else the block's base)
+  gdouble *lay;  // UNIFORM: 4096 bytes into the wave's 64-column block of the layer arrays 
   unsigned col; // this lane's column
   unsigned coff;     // col * 8: byte offset of the column inside a row of the scalar / hand-over blocks
-  unsigned lcoff;    // lane * 8: byte offset of the column inside a row of its 64-column block (SAMSIM_BLOCKED)
+  unsigned lcoff;    // lane * 8: byte offset of the column inside a row of its 64-column block
   unsigned rstride;  // UNIFORM ncol * 8: bytes per row
   size_t astride;    // UNIFORM nlayer * ncol * 8: bytes per layer array
   size_t ncol;
@@ -241,34 +230,18 @@ struct Col {
 // Row (a, k) of the layer block starts at a wave-uniform address whenever k is uniform (all top-down loops, and the
 // bottom-up loops that run from the wave maximum of N_active); the lane only adds its 32-bit column offset, which lets
 // the compiler use scalar-base addressing (global_load ... v_off, s[base]) instead of a 64-bit VGPR address per array.
-// SAMSIM_FAST_DIV: quotients that share a divisor are formed through one reciprocal (Expulsion: /thick three times and the two
-// density constants; getT: /S_br and /S_br**2; S_abs/m and H_abs/m; H/c_l; the constant kappa_l*mu), each within 1-2 ulp of the
-// quotient the reference forms -- the parity bar is 1e-6 relative.  With the loads pipelined the sweeps are bound by their
-// dependent FP64 chains, and an IEEE division is an 11-instruction chain: 67.5 ms per launch of the default bench with the
-// shared reciprocals, 73.1 ms with the reference's quotients (=0).  Levels 2 and 3 (default) change no bits any more: they form
-// the reciprocals (2) and the other quotients of the fused sweeps (3) by the compiler's own Newton sequence without the operand
-// scaling and special-case fix-up around it, see recip() / quot(): 65.4 -> 63.4 ms (same box).
-#ifndef SAMSIM_FAST_DIV
-#define SAMSIM_FAST_DIV 3
-#endif
-// SAMSIM_HORNER: the liquidus polynomial in Horner form (5 operations instead of 9 per evaluation, about six evaluations per
-// layer-cell; 1 % on the default bench); 0 = the reference's c2*T + c3*T**2 + c4*T**3
-// SAMSIM_THICK_RULE: the semi-adaptive grid (mo_layer_dynamics.f90) keeps every layer but the first at thick_0, except the
-// N_middle elastic layers, which all share one value (they receive the same increments in the same order).  Where a column's
-// thicknesses follow that rule (COLF_REGULAR, checked whenever the full first sweep runs) the fused sweeps and the Beer-law pass
-// form thick(k) from thick(1), thick(N_top+1) and thick_0 instead of streaming the array: three of the fourteen row accesses per
-// layer-cell.  A column that does not follow it (a hand-made state) loads the array; 0 = always load.
-#ifndef SAMSIM_THICK_RULE
-#define SAMSIM_THICK_RULE 1
-#endif
-// SAMSIM_DAHEAD: how many layers ahead of the arithmetic the fused down sweep requests its operands (2 or 3)
-#ifndef SAMSIM_DAHEAD
-#define SAMSIM_DAHEAD 2
-#endif
-// SAMSIM_DUNROLL: the interior loop of the fused down sweep handles two layers per trip (see there)
-#ifndef SAMSIM_DUNROLL
-#define SAMSIM_DUNROLL 1
-#endif
+//
+// Arithmetic choices of the fused sweeps (each an ulp-level deviation from the reference's operation order; the parity bar is 1e-6
+// relative, observed against the reference's own records <= 1e-11 on one-day windows, tests/test_gpu_reference_windows.py):
+//  * quotients that share a divisor go through one reciprocal (Expulsion: /thick three times and the two density constants; getT:
+//    /S_br and /S_br**2; S_abs/m and H_abs/m; H/c_l; the constant kappa_l*mu); recip() / quot() of samsim_div.h are the compiler's
+//    own Newton sequence without the operand scaling and special-case fix-up around it (the divisors are normal-range numbers);
+//  * the liquidus polynomial in Horner form (5 operations instead of 9 per evaluation);
+//  * the thicknesses of a regular column from the grid rule: the semi-adaptive grid (mo_layer_dynamics.f90) keeps every layer but
+//    the first at thick_0, except the N_middle elastic layers, which all share one value (they receive the same increments in the
+//    same order).  Where a column follows that rule (COLF_REGULAR, checked by the full first sweep after samsim_set_state and after
+//    every regrid) the sweeps form thick(k) from thick(1), thick(N_top+1) and thick_0 instead of streaming the array; a column that
+//    does not follow it (a hand-made state) loads the array and takes the unfused order.
 // RARE_CHUNK: the sweeps of the melt season (flushing, freeboard, the unfused order of a step with thin snow or possible flooding)
 // walk a column with a per-lane trip count and little arithmetic per layer; with a row requested where it is used every
 // iteration waits a full memory latency (2 us under load against 0.1-0.5 us of work).  They request RARE_CHUNK rows at a time
@@ -276,47 +249,22 @@ struct Col {
 #ifndef RARE_CHUNK
 #define RARE_CHUNK 8
 #endif
-// SAMSIM_UAHEAD: how many layers ahead of the arithmetic the fused up sweep requests its operands (2 or 3)
-#ifndef SAMSIM_UAHEAD
-#define SAMSIM_UAHEAD 2
-#endif
-// SAMSIM_FUSE_COUPLING: thin-snow coupling inside the fused down sweep (see there); 0 = columns with thin snow take the unfused order
-#ifndef SAMSIM_FUSE_COUPLING
-#define SAMSIM_FUSE_COUPLING 1
-#endif
-// SAMSIM_RTH_RULE: the fused up sweep takes 1/thick of a regular column's layers from two reciprocals formed once per sweep
-#ifndef SAMSIM_RTH_RULE
-#define SAMSIM_RTH_RULE 1
-#endif
+// SAMSIM_PATH_MODE 2 (the product): one order of the step per wave, see column_step; 1 = always the unfused order (the checker
+// build of tools/path_equiv.py, which shows on the GPU that the two orders give a column the same bits)
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
-// SAMSIM_LAUNDER_COL: the column index is re-declared to the optimiser at every time step (see samsim_step_kernel)
-#ifndef SAMSIM_LAUNDER_COL
-#define SAMSIM_LAUNDER_COL 1
-#endif
-#ifndef SAMSIM_HORNER
-#define SAMSIM_HORNER 1
-#endif
-#ifndef LAY
-// Address of element (a, k) = <uniform base of array a> + <32-bit byte offset of (row k, this lane's column)>: the form the
-// hardware loads with a scalar base and ONE 32-bit offset register per row (global_load ... v_off, s[base:base+1]); all arrays
-// of a row share the offset register.  (A 64-bit per-lane address for every array costs two registers each and 64-bit vector
-// arithmetic per access.)  Needs nlayer * ncol * 8 < 4 GiB per handle; samsim_create checks it.
-#if SAMSIM_BLOCKED
+static_assert(SAMSIM_BLOCK == 64, "the blocked layer layout, launch() and DEV_LAY_INDEX are written for one 64-lane wave per column block");
+// Address of element (a, k): one 32-bit offset register per row serves all arrays of the row (a 64-bit per-lane address for every
+// array costs two registers each and 64-bit vector arithmetic per access).
 // Blocked layout (samsim_device.h): c.lay points 4096 bytes into the wave's own column block, so that array a of layer row k is at
 // c.lay + (k-1)*DEV_ROWB + (a*512 - 4096) + lane*8: sixteen arrays within the signed 13-bit immediate of one row address.
 // LAY takes any k (one 32-bit offset register per row, the lane's part included); LAYU is for a wave-uniform k: the row address is
 // scalar arithmetic and the vector offset is the lane's constant c.lcoff.
 #define LAY(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(unsigned)(((unsigned)(k) - 1u) * (unsigned)DEV_ROWB + c.lcoff) + (ptrdiff_t)((int)(a) * 512 - 4096)))
 #define LAYU(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(((unsigned)(k) - 1u) * (unsigned)DEV_ROWB) + (size_t)c.lcoff + (ptrdiff_t)((int)(a) * 512 - 4096)))
-#else
-#define ROWOFF(k) ((unsigned)(((unsigned)((k) - 1)) * c.rstride + c.coff))
-#define LAY(a, k) (*(gdouble *)((gchar *)c.lay + (size_t)(a) * c.astride + (size_t)ROWOFF(k)))
-#define LAYU(a, k) LAY(a, k)
-#endif
+// hand-over block [DEV_NSPEC][ncol]: scalar base + 32-bit byte offset, like GSI (samsim_create bounds ncol for both)
 #define SPEC(i) (*(gdouble *)((gchar *)c.spec + (size_t)(unsigned)((unsigned)(i) * c.rstride + c.coff)))
-#endif
 #define STOPC(code, layer)            \
   do {                                \
     if (!c.status) {                  \
@@ -352,11 +300,7 @@ __device__ __forceinline__ bool wave_leader() { return (int)__lane_id() == __ffs
 // (the C semantics for NaN and signed zeros differ from the instruction's), and every vector instruction costs the same four
 // cycles: the sweeps clamp some twenty times per layer-cell.  For ordered operands the value is the same (max(-0, +0) may come out
 // as +0 instead of -0: equal numbers); a NaN operand loses against a number in both forms where the number is the constant.
-// SAMSIM_MINMAX_ASM 0 = the ternaries.
-#ifndef SAMSIM_MINMAX_ASM
-#define SAMSIM_MINMAX_ASM 1
-#endif
-#if SAMSIM_MINMAX_ASM && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double dmax(double a, double b) {
   double r;
   if (__builtin_constant_p(b) && b == 0.0) asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
@@ -393,35 +337,20 @@ __device__ __forceinline__ double max_c(double a, double c_const) { return a > c
 #endif
 // S_bu = S_abs/m and H = H_abs/m of one layer, mo_grotz.f90:298-299, 593-594
 __device__ __forceinline__ void per_mass(double S_abs, double H_abs, double m, double &S_bu, double &H) {
-#if SAMSIM_FAST_DIV
   const double rm = recip(m);
   S_bu = S_abs * rm;
   H = H_abs * rm;
-#else
-  S_bu = S_abs / m;
-  H = H_abs / m;
-#endif
 }
 __device__ __forceinline__ double per_mass(double S_abs, double m) { return S_abs / m; }
 
 // func_S_br without / with the S_bu clamp, mo_thermo_functions.f90:308-360.  flang lowers T**2._wp and T**3._wp
 // to multiplications (verified bit for bit against the flang build), so do we.
 __device__ __forceinline__ double S_br_poly(const Salt &s, double T) {
-#if SAMSIM_HORNER == 2
-  return T * __builtin_fma(T, __builtin_fma(T, s.c4, s.c3), s.c2);   // Horner with fused multiply-adds (one routine for every caller)
-#elif SAMSIM_HORNER
   return T * (s.c2 + T * (s.c3 + T * s.c4));
-#else
-  return 0.0 + s.c2 * T + s.c3 * (T * T) + s.c4 * (T * T * T);
-#endif
 }
 __device__ __forceinline__ double S_br_clamped(const Salt &s, double T, double S_bu) {
   double v = S_br_poly(s, T);
-#if SAMSIM_CLAMP_MAX
   return dmax(v, S_bu);   // one v_max_f64 for the compare and two 32-bit selects of `v < S_bu ? S_bu : v`: the same number for numbers
-#else
-  return v < S_bu ? S_bu : v;
-#endif
 }
 // func_ddT_S_br, mo_thermo_functions.f90:380-414 (derivative-only clamp below -20 C)
 __device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
@@ -435,14 +364,12 @@ __device__ __forceinline__ double ddT_S_br(const Salt &s, double T) {
 // clamps S_br at 1e-9, the ones in the loop at 1e-10, as in the reference)
 __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_bu, double T_0, double sb, double sb_floor,
                                              double &f, double &ddT_f) {
-#if SAMSIM_FAST_DIV
   if (sb > 0.0001) {  // neither clamp is active: one reciprocal serves both quotients
     const double inv = recip(sb);
     f = -latent_heat - H + latent_heat * S_bu * inv + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
     ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) * (inv * inv);
     return;
   }
-#endif
   f = -latent_heat - H + latent_heat * S_bu / dmax(sb, sb_floor) + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
   ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
 }
@@ -453,38 +380,12 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 // reciprocals above), 8 fewer instructions and 8 fewer links in the dependent chain per evaluation -- and getT runs 3.6
 // evaluations per layer-cell on the bench ensemble, all of them on the critical path of the up sweep.  Only taken where the
 // reference's clamps of S_br (1e-9 / 1e-10) are inactive (sb > 1e-4); 0 = two divisions.
-#ifndef SAMSIM_NEWTON1
-#define SAMSIM_NEWTON1 1
-#endif
 // SAMSIM_CLAMP_MAX: the clamps of the liquidus and of Expulsion as single v_max_f64
-#ifndef SAMSIM_CLAMP_MAX
-#define SAMSIM_CLAMP_MAX 1
-#endif
-#ifndef SAMSIM_NEWTON_FMA
-#define SAMSIM_NEWTON_FMA 1
-#endif
 // one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1
 __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
-#if SAMSIM_NEWTON_FMA
   // the same step with fused multiply-adds (one rounding per a*b+c instead of two: 27 vector instructions instead of 41 per
   // evaluation, 3.6 evaluations per layer-cell, all on the critical path of the up sweep); each iterate within an ulp or two
   // of the unfused form's, like the other ulp-level changes of this file
-#if SAMSIM_NEWTON_FMA == 2
-  // (the constants as scalar operands: fma_c above; 28 vector instructions per evaluation where the compiler's choice of
-  // accumulating multiply-adds took 35)
-  const double sbf = T_0 * fma_c(T_0, T_0 * s.c4 + s.c3, s.c2);
-  if (sbf > 0.0001) {
-    const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
-    const double A = __builtin_fma(T_0, T_0 * (0.5 * c_s_beta) + c_s, -latent_heat - H);
-    const double B = c_s_beta * T_0 + c_s;
-    const double num = __builtin_fma(A, sb2, LS * sbf);
-    const double Tc = max_c(T_0, -20.0);
-    const double dd = fma_c(Tc, Tc * (3.0 * s.d4) + 2.0 * s.d3, s.d2);
-    const double den = __builtin_fma(B, sb2, -(LS * dd));
-    T_new = T_0 - quot(num, den);
-    return fabs(num) > sb2;
-  }
-#else
   const double sbf = T_0 * __builtin_fma(T_0, __builtin_fma(T_0, s.c4, s.c3), s.c2);
   if (sbf > 0.0001) {
     const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
@@ -497,10 +398,7 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
     T_new = T_0 - quot(num, den);
     return fabs(num) > sb2;
   }
-#endif
-#endif
   const double sb = S_br_poly(s, T_0);
-#if SAMSIM_NEWTON1 && SAMSIM_FAST_DIV
   if (sb > 0.0001) {
     const double sb2 = sb * sb, LS = latent_heat * S_bu;
     const double A = -latent_heat - H + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
@@ -510,7 +408,6 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
     T_new = T_0 - quot(num, den);
     return fabs(num) > sb2;
   }
-#endif
   double f, ddT_f;
   newton_terms(s, H, S_bu, T_0, sb, sb_floor, f, ddT_f);
   T_new = T_0 - quot(f, ddT_f);
@@ -519,11 +416,7 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
 
 // H/c_l: the temperature of pure brine of enthalpy H (first line of getT, mo_thermo_functions.f90:84)
 __device__ __forceinline__ double T_liquid(double H) {
-#if SAMSIM_FAST_DIV
   return H * (1.0 / c_l);
-#else
-  return H / c_l;
-#endif
 }
 
 // getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
@@ -587,19 +480,12 @@ __device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_b
 // x**3.10 of the permeability law (mo_grav_drain.f90:105, mo_flush.f90:119,128, mo_flood.f90:73) as exp(3.1*log(x)):
 // within ~4e-15 relative of the correctly rounded pow() the reference links (|3.1*log x| <= 22 for x <= 1000), at a
 // third of its instructions and without the double-double constant tables that push the layer loops into spills.
-#ifndef SAMSIM_POW
-#define SAMSIM_POW 1
-#endif
-#if SAMSIM_POW
 }  // namespace
 #define SP_QUOT(a, b) quot(a, b)
 #include "samsim_pow.h"
 namespace {
 // x*x*x * exp(0.1*log(x)) with a plain logarithm: within ~4 ulp of the correctly rounded power (samsim_pow.h)
 __device__ __forceinline__ double pow_3p1(double x) { return sp_pow_3p1(x); }
-#else
-__device__ __forceinline__ double pow_3p1(double x) { return exp(3.10 * log(x)); }
-#endif
 
 // func_density, mo_functions.f90:51-62
 __device__ double func_density(double T, double S) {
@@ -707,7 +593,7 @@ __device__ __forceinline__ double thick_by_rule(int k, int n_top, int n_middle, 
 struct ThickRule { bool reg; int n_top, n_middle; double th_mid, thick_0; };
 #define THICK_RULE_INIT(tr)                                                                                   \
   ThickRule tr;                                                                                               \
-  tr.reg = SAMSIM_THICK_RULE && (c.flags & COLF_REGULAR) != 0; tr.n_top = x.p->cfg.n_top; tr.n_middle = x.p->cfg.n_middle; \
+  tr.reg = (c.flags & COLF_REGULAR) != 0; tr.n_top = x.p->cfg.n_top; tr.n_middle = x.p->cfg.n_middle; \
   tr.thick_0 = x.p->cfg.thick_0; tr.th_mid = LAY(SAMSIM_A_THICK, tr.n_top + 1)
 #define THICK_AT(tr, kk) ((tr.reg && (kk) >= 2) ? thick_by_rule(kk, tr.n_top, tr.n_middle, tr.th_mid, tr.thick_0) : LAY(SAMSIM_A_THICK, kk))
 
@@ -1001,30 +887,13 @@ struct Expelled { double psi_s, psi_l, psi_g, V_ex; };
 // its argument alone, so the bits are the same wherever it is formed)
 __device__ __forceinline__ Expelled expulsion(double phi, double thick, double m, double rth) {
   Expelled e;
-#if SAMSIM_FAST_DIV
   const double V_s = m * phi * (1.0 / rho_s), V_l = m * (1.0 - phi) * (1.0 / rho_l);
-#if SAMSIM_CLAMP_MAX
   e.V_ex = dmax(V_l + V_s - thick, 0.0);   // (a sum above thick leaves a positive difference, one at or below it none)
-#else
-  e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
-#endif
   e.psi_s = V_s * rth;
   e.psi_l = (V_l - e.V_ex) * rth;
   e.psi_g = (thick - V_l - V_s + e.V_ex) * rth;
-#else
-  const double V_s = m * phi / rho_s, V_l = m * (1.0 - phi) / rho_l;
-  e.V_ex = (V_s + V_l > thick) ? (V_l + V_s - thick) : 0.0;
-  e.psi_s = V_s / thick;
-  e.psi_l = (V_l - e.V_ex) / thick;
-  e.psi_g = (thick - V_l - V_s + e.V_ex) / thick;
-#endif
-#if SAMSIM_CLAMP_MAX
   e.psi_l = dmax(e.psi_l, 0.0);
   e.psi_g = dmax(e.psi_g, 0.0);
-#else
-  if (e.psi_l < 0.0) e.psi_l = 0.0;
-  if (e.psi_g < 0.0) e.psi_g = 0.0;
-#endif
   return e;
 }
 
@@ -1060,11 +929,7 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       } else {
         ray = grav_f * rho_l * bbeta * d_S_br * height * dmin(r.minp, r.perm_bot);
       }
-#if SAMSIM_FAST_DIV
       ray = ray * (1.0 / (kappa_l * mu));
-#else
-      ray = ray / (kappa_l * mu);
-#endif
       ray = dmax(ray, 0.0);
       if (!sparse_rows) {
         LAYU(SAMSIM_A_RAY, k) = ray;
@@ -1094,7 +959,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   struct L4 { double H, m, th, S; };
   bool regular = true;
   const double th_mid_rule = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-  const bool check_col = !SAMSIM_THICK_RULE || (c.flags & COLF_REGULAR) == 0 || (c.flags & (COLF_RESTART | COLF_REGRID)) != 0;
+  const bool check_col = (c.flags & COLF_REGULAR) == 0 || (c.flags & (COLF_RESTART | COLF_REGRID)) != 0;
   const bool check_wave = __ballot(check_col) != 0ull;
   const int kmax = wave_max(Na);
   auto run = [&](auto check_tag) {
@@ -1534,16 +1399,10 @@ __device__ RARE void sweep_beer(Col &c, const Ctx &x, double beer0) {
   const samsim_config &g = x.p->cfg;
   const int Na = c.Na;
   double temp2 = beer0, e = 0.0, th_prev = -1.0;
-#if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-#endif
   for (int k = 1; k <= Na; ++k) {
-#if SAMSIM_THICK_RULE
     const double thick = (regular && k >= 2) ? thick_by_rule(k, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, k);
-#else
-    const double thick = LAYU(SAMSIM_A_THICK, k);
-#endif
     if (thick != th_prev) { e = exp(-extinc * thick); th_prev = thick; }
     if (k == Na) c.frad = temp2 - temp2 * e;
     temp2 = temp2 * e;
@@ -1649,9 +1508,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // layers.  That test now forms S_br(j+1) from the request buffer on demand.)
   struct Ld { double T, S_abs, m, H_abs, ray; };
   struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
-#if SAMSIM_THICK_RULE
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-#endif
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAYU(SAMSIM_A_T, j);
@@ -1666,11 +1523,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   auto finish = [&](const Ld &l, int j) -> Raw {
     Raw r;
     r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.ray = l.ray;
-#if SAMSIM_THICK_RULE
     r.thick = (j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
-#else
-    r.thick = LAYU(SAMSIM_A_THICK, j);
-#endif
     per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
@@ -1839,8 +1692,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // (sub_heat_fluxes' first part reads layer 1, the snow and the forcing, none of which the rest of this sweep touches), hence
   // T_top, fl_Q(1) and fl_Q_snow; the freezing point of layer 1 (S_abs(1), m(1) stay as they are unless wet snow adds slush);
   // the snow's enthalpy after the heat fluxes, hence whether the second snow_thermo of the step can find it wet.  The rows are
-  // skipped only when none of the conditions can hold, so a late reader never meets a column without them (they still
-  // check -- code 9001 -- but the check cannot fire; tests/test_gpu_parity.py drives 4 096 columns through a melt season on it).
+  // skipped only when none of the conditions can hold, so a late reader never meets a column without them (refill_psi_rows is
+  // the safety net; tools/melt_ensemble_status.py drives 4 096 columns through a melt season and freeze-up and counts its calls).
   if (decide_psi && Na >= 3) {
     surface_flux<K>(c, x);
     surface_done = true;
@@ -1858,7 +1711,6 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     store_psi = store_default || decide_psi;   // (a deciding sweep over fewer than three layers has nothing left to skip)
   }
   c.psi_full = store_psi;
-#if SAMSIM_DUNROLL
   // The interior layers 3 <= j < N_active, two per trip: the two request buffers swap roles from one layer to the next, so with
   // both layers in one loop body no buffer is copied into the other (and the hand-over of layer j to C(j) of the next layer is a
   // renaming): the single-layer loop spent 35 of its 265 vector instructions on those copies.
@@ -1876,14 +1728,12 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
         layer(j + 1, ahead2, std::false_type{}, std::false_type{});
         raw = finish(ahead2, j + 2);
       }
-#ifndef SAMSIM_DUNROLL_NOELSE
       else if (j < Na) {                               // layer j is the column's last interior layer
         ST_COUNT(CT_DOWN_TRIPS, 1);
         ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
         layer(j, ahead, std::false_type{}, std::false_type{});
         raw = finish(ahead, j + 1);
       }
-#endif
       ISA_MARK("D_ITER_END");
     }
     if (j < jmax && j < Na) {                            // odd number of interior layers in the longest column of the wave
@@ -1892,18 +1742,6 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       raw = finish(ahead, j + 1);
     }
   }
-#else
-  for (int j = 3; j < jmax; ++j) {                     // the interior layers 3 <= j < N_active
-    ISA_MARK("D_ITER_BEGIN");
-    ST_MARK(ST_DFUSED);
-    if (j >= Na) continue;
-    ST_COUNT(CT_DOWN_TRIPS, 1);
-    request(j);
-    layer(j, ahead, std::false_type{}, std::false_type{});
-    advance(j);
-    ISA_MARK("D_ITER_END");
-  }
-#endif
   layer(Na, ahead, std::true_type{}, std::false_type{});                  // the bottom layer (this sweep only runs with N_active >= 2)
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
@@ -2082,29 +1920,17 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // memory operations in order, and the compiler can only wait for "all but the N youngest" when every path through the loop
   // body issues the same operations -- one conditional request and it falls back to draining them all.
   struct UL { double th, H, m, S; };
-#if SAMSIM_THICK_RULE
   const bool regular = (c.flags & COLF_REGULAR) != 0;
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-#if SAMSIM_RTH_RULE
   // 1/thick of the two thicknesses of the grid rule, once per sweep (an irregular column forms it per layer)
   const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
-#endif
-#endif
   auto load_ul = [&](int j) -> UL {
     UL r;
-#if SAMSIM_THICK_RULE
     r.th = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, j);
-#else
-    r.th = LAYU(SAMSIM_A_THICK, j);
-#endif
     r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
     return r;
   };
   UL cur = load_ul(Na), nxt = load_ul(Na >= 2 ? Na - 1 : 1), nn = nxt;   // layers k, k-1, k-2
-#if SAMSIM_UAHEAD == 3
-  nn = load_ul(Na >= 3 ? Na - 2 : 1);
-  UL n3 = nn;                                                              // layer k-3
-#endif
   bool alive = true;
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
   // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
@@ -2163,11 +1989,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-#if SAMSIM_RTH_RULE && SAMSIM_THICK_RULE
       const double rth_k = regular ? ((k > g.n_top && k <= g.n_top + g.n_middle) ? rth_mid : rth_0) : recip(th_k);   // (k >= 2 here)
-#else
-      const double rth_k = recip(th_k);
-#endif
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, rth_k, r, true);
     }
     ST_MARK(ST_U_TAIL);
@@ -2177,15 +1999,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     ISA_MARK("U_ITER_BEGIN");
     ST_MARK(ST_UP);
     if (k > Na) continue;
-#if SAMSIM_UAHEAD == 3
-    n3 = load_ul(k >= 4 ? k - 3 : 1);
-    body(k, std::false_type{});
-    cur = nxt; nxt = nn; nn = n3;
-#else
     nn = load_ul(k >= 3 ? k - 2 : 1);
     body(k, std::false_type{});
     cur = nxt; nxt = nn;
-#endif
     ISA_MARK("U_ITER_END");
   }
   body(1, std::true_type{});
@@ -2752,9 +2568,10 @@ __device__ RARE void prescribe_salinity(Col &c, const Ctx &x) {
     k = k - 1;
     S_bu1 = 0.0;
   }
-  // both loops ending above layer 1 takes SUMs that shrink as layers are added; the reference would then fall back on the
-  // S_bu array of the first sweep, which is not kept here
-  if (k > 1) STOPC(9001, k);
+  // Both loops ending above layer 1 takes SUMs that shrink as layers are added (a negative or NaN thickness).  The reference then
+  // leaves S_bu(2..k) as the refresh of mo_grotz.f90:333 set them and forms S_abs = S_bu*m from that; the unfused order, which a
+  // prescribed profile always takes, has that row in the array (sweep_expulsion_transfer).
+  for (int j = k; j > 1; --j) LAY(SAMSIM_A_S_ABS, j) = LAY(SAMSIM_A_S_BU, j) * LAY(SAMSIM_A_M, j);
   if (Na > 1) LAY(SAMSIM_A_S_ABS, Na) = Sb * LAY(SAMSIM_A_M, Na);
   else S_bu1 = Sb;
   LAY(SAMSIM_A_S_ABS, 1) = S_bu1 * LAY(SAMSIM_A_M, 1);
@@ -2899,6 +2716,29 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
     sweep_heat_down<K>(c, x);
 }
 
+// Safety net of the stored-row decision (sweep_down_fused): a late reader of psi_s / psi_l / psi_g -- func_freeboard, flush3 -- in a
+// step whose down sweep skipped the rows of layers >= 3.  The sweep evaluates those readers' conditions exactly before it skips
+// (profiles/r3_melt_ensemble_status.json: a free-running ensemble through melt season and freeze-up never gets here; the stamps
+// build counts the calls, CT_REFILL), so this is not on any tested trajectory; should a column ever arrive, it keeps running:
+// the rows are filled by one Expulsion pass over the finished layers (temperature of the second sweep, current masses) -- the
+// values the next step's first sweep will form -- instead of the column being stopped.
+template <class K>
+__device__ RARE void refill_psi_rows(Col &c, const Ctx &x) {
+  ST_COUNT(CT_REFILL, (unsigned long long)__popcll(__ballot(1)));
+  THICK_RULE_INIT(tr);
+  for (int k = 3; k <= c.Na; ++k) {
+    const double m = LAY(SAMSIM_A_M, k), thick = THICK_AT(tr, k);
+    double S_bu, H;
+    per_mass(LAY(SAMSIM_A_S_ABS, k), LAY(SAMSIM_A_H_ABS, k), m, S_bu, H);
+    const double S_br = S_br_clamped(x.salt, LAY(SAMSIM_A_T, k), S_bu);
+    const Expelled e = expulsion(phi_from_T(x.salt, H, S_bu, S_br), thick, m, recip(thick));
+    LAY(SAMSIM_A_PSI_S, k) = e.psi_s;
+    LAY(SAMSIM_A_PSI_L, k) = e.psi_l;
+    LAY(SAMSIM_A_PSI_G, k) = e.psi_g;
+  }
+  c.psi_full = true;
+}
+
 // ---------------------------------------------------------------- one time step, mo_grotz.f90:182-835
 template <class K>
 __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, double time, int tc, bool out_step, bool next_out,
@@ -2952,13 +2792,11 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool coupling = (CL(m_snow) > 0.0 && CL(thick_snow) < g.thick_min);
   const bool flood_possible = (CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                CL(m_snow) > c.buoy_s * (rho_l - rho_s));
-  // (a thin snow cover no longer needs the unfused order: the fused down sweep couples it to the top layer in place, SAMSIM_FUSE_COUPLING)
-  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && (SAMSIM_FUSE_COUPLING || !coupling) && !flood_possible &&
+  // (a thin snow cover no longer needs the unfused order: the fused down sweep couples it to the top layer in place)
+  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && !flood_possible &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2)
-#if SAMSIM_THICK_RULE
                      && (c.flags & COLF_REGULAR) != 0   // the fused down sweep takes the thicknesses from the grid rule only
-#endif
       ;
   // SAMSIM_PATH_MODE 2 (default): one path per wave.  A wave whose columns disagree runs both paths one after the other, each
   // with part of its lanes idle -- the normal state of a melt season, when some column of almost every wave has thin snow or a
@@ -2987,7 +2825,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // none of which the down sweep changes, so they can run first
     testcase_scalars<K>(c, x, g, time);
     // with a thin snow cover somewhere in the wave the radiation header waits for the coupling inside the sweep (it reads T_snow)
-    const bool late_rad = SAMSIM_FUSE_COUPLING && __ballot(coupling) != 0ull;
+    const bool late_rad = __ballot(coupling) != 0ull;
     double beer0 = 0.0;
     if (!late_rad) {
       beer0 = radiation_header<K>(c, x, time, tc);
@@ -2998,10 +2836,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // finished top layer; without it (flush_flag 1) only the vital signs at the next output point and a get_state after the
     // launch read them
     bool store_default = true, decide_psi = false;
-#ifndef SAMSIM_STORE_PSI_ALWAYS
     if (K::fixed && K::boundflux_flag == 2 && K::flush_flag == 5) { store_default = next_out || last_step; decide_psi = true; }
     if (K::fixed && K::flush_flag == 1) store_default = next_out || last_step;
-#endif
     // fl_rad(N_active) enters the conductive update of every layer (mo_heat_fluxes.f90:282-285), which the down sweep applies as
     // it goes: the Beer-law product over the layer thicknesses (a pass over one array) comes first
     if (do_beer && !late_rad) sweep_beer<K>(c, x, beer0);
@@ -3054,7 +2890,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);
     // the reference evaluates func_freeboard first (:636); its value is only read under the melt condition (:637)
     if (psi_s1 < psi_s_top_min || T_surf >= T_freeze) {
-      if (!c.psi_full) STOPC(9001, 0);
+      if (!c.psi_full) refill_psi_rows<K>(c, x);
       ST_COUNT(CT_L_FREEBOARD, (unsigned long long)__popcll(__ballot(1)));
       GS(FREEBOARD) = func_freeboard<K>(c, x);
       fb_valid = true;
@@ -3098,7 +2934,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
                                CL(melt_thick) + CL(melt_thick_snow) > 0.000000000001);
-  if (flush_possible && !c.psi_full) STOPC(9001, 0);
+  if (flush_possible && !c.psi_full) refill_psi_rows<K>(c, x);
   if (flush_possible && !fb_valid) GS(FREEBOARD) = func_freeboard<K>(c, x);
   // (the accumulators sit in the scalar block: x + 0 is x, so nothing is read or written while nothing melts)
   if (CL(melt_thick) != 0.0) GS(MELT_OUT1) = GS(MELT_OUT1) + CL(melt_thick);
@@ -3216,18 +3052,14 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   else x.salt = Salt{-17.6, -0.389, -0.00362, -17.6, -0.389, -0.00362};
 
 #if SAMSIM_STAMPS
-  __shared__ unsigned long long st_lds[32];
-  if (threadIdx.x < 32) st_lds[threadIdx.x] = 0;
+  __shared__ unsigned long long st_lds[48];
+  if (threadIdx.x < 48) st_lds[threadIdx.x] = 0;
   __syncthreads();
   x.st.acc = st_lds;
   x.st.t0 = __builtin_amdgcn_s_memtime();
 #endif
   Col c;
-#if SAMSIM_BLOCKED
   c.lay = (gdouble *)((gchar *)lay + (size_t)blk * ((size_t)p.cfg.nlayer * DEV_ROWB) + 4096);
-#else
-  c.lay = (gdouble *)lay;
-#endif
   c.col = (unsigned)col;
   c.coff = (unsigned)col * 8u;
   c.lcoff = threadIdx.x * 8u;
@@ -3293,20 +3125,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
       // reloads one from scratch memory (= HBM) at every use.  Passing the index through an empty asm makes them values of the
       // step: each is formed where it is used (two or three vector instructions) and nothing is carried.
       long long col_step = col;
-#if SAMSIM_LAUNDER_COL
       asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(c.lcoff), "+v"(col_step));
-#endif
-#if SAMSIM_LAUNDER_COL >= 2
-      // the same for the wave-uniform strides: row and array bases are formed on the scalar unit where a sweep starts, instead of
-      // being kept (and moved in and out of spill lanes) for the whole launch
-      {
-        unsigned rs = __builtin_amdgcn_readfirstlane(c.rstride);
-        unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)c.astride), ahi = __builtin_amdgcn_readfirstlane((unsigned)(c.astride >> 32));
-        asm volatile("" : "+s"(rs), "+s"(alo), "+s"(ahi));
-        c.rstride = rs;
-        c.astride = ((size_t)ahi << 32) | (size_t)alo;
-      }
-#endif
       column_step<K>(c, x, col_step, time, tc, out_step, next_out, s + 1 == p.nsteps);
     }
     time = time + p.cfg.dt;
@@ -3336,7 +3155,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
 #if SAMSIM_STAMPS
   ST_MARK(ST_TAIL);
   __syncthreads();
-  if (threadIdx.x < 32 && st_lds[threadIdx.x]) atomicAdd(&g_stamps[threadIdx.x], st_lds[threadIdx.x]);
+  if (threadIdx.x < 48 && st_lds[threadIdx.x]) atomicAdd(&g_stamps[threadIdx.x], st_lds[threadIdx.x]);
 #endif
 }
 

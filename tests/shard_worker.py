@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def ensemble_shard(col0, n, nsteps, device=0, launches=1):
+def ensemble_shard(col0, n, nsteps, device=0, launches=1, split_blocks=None):
     import samsim_amd
     from samsim_amd import testcases as tcs
     from tests.helpers import load_checkpoint, sheba_forcing
@@ -21,6 +21,8 @@ def ensemble_shard(col0, n, nsteps, device=0, launches=1):
     g.set_forcing(*sheba_forcing(), dT, ps)
     g.set_state(st1.replicate(n))
     g.set_clock(**clock)
+    if split_blocks is not None:
+        g.set_launch_split(split_blocks, 4)
     for _ in range(launches):
         g.step(nsteps)
     st, status = g.get_state(), g.get_status()[0]

@@ -74,11 +74,20 @@ def test_unsupported_configurations_are_refused_before_any_device_call():
 
 
 def test_handle_size_limit_is_checked_before_any_device_call():
-    """one handle addresses a layer array with 32-bit byte offsets: nlayer * ncol * 8 >= 4 GiB is SAMSIM_ERR_ARG (-1)"""
-    cfg, _ = tcs.testcase4(1)
-    with pytest.raises(samsim_amd.SamsimError) as e:
-        samsim_amd.hip_solver(cfg, (1 << 29) // int(cfg.nlayer) + 1)
-    assert e.value.code == -1
+    """one handle addresses its [38][ncol] scalar block with 32-bit byte offsets: 38 * ncol * 8 >= 4 GiB is SAMSIM_ERR_ARG (-1),
+    whatever nlayer is (a thin column does not lift the bound: the layer block is not what limits a handle)"""
+    from samsim_amd.capi import NSCAL
+    max_ncol = ((1 << 32) - 1) // (8 * NSCAL)
+    text = open(os.path.join(ROOT, "include", "samsim.h")).read()
+    assert "#define SAMSIM_MAX_NCOL ((int64_t)(((1ull << 32) - 1) / (8ull * SAMSIM_NSCAL)))" in text
+    for nlayer, n_top, n_bottom in ((100, 20, 20), (20, 5, 5)):
+        cfg, _ = tcs.testcase4(1, nlayer=nlayer, n_top=n_top, n_bottom=n_bottom)
+        with pytest.raises(samsim_amd.SamsimError) as e:
+            samsim_amd.hip_solver(cfg, max_ncol + 1)
+        assert e.value.code == -1, nlayer
+        with pytest.raises(samsim_amd.SamsimError) as e:    # one column fewer passes the size check (and stops at the device check
+            samsim_amd.hip_solver(cfg, 1 << 40)             # here, or at the allocation on a GPU box): not probed with a real size
+        assert e.value.code == -1
 
 
 def test_product_does_not_reference_the_oracle():

@@ -131,13 +131,13 @@ def test_sheba_melt_season_one_day():
     og, oo = g.run_to_output(), o.run_to_output()
     assert og.step == oo.step
     for name in ["T", "psi_s", "psi_l", "S_bu", "thick", "perm", "flush_v", "flush_h"]:
-        assert rel_err(og.arr(name), oo.arr(name), 1e-7 if name != "perm" else 1e-30) <= 1e-5, name
+        assert rel_err(og.arr(name), oo.arr(name), 1e-7 if name != "perm" else 1e-30) <= RTOL, name
     for name in ["freeboard", "thick_snow", "T_snow", "thickness", "bulk_salin", "melt_out1", "melt_out2"]:
-        assert rel_err(og.sc(name), oo.sc(name), 1e-7) <= 1e-5, name
-    check(g, o, "sheba melt season", rtol=1e-5)
+        assert rel_err(og.sc(name), oo.sc(name), 1e-7) <= RTOL, name
+    check(g, o, "sheba melt season")
     g.step(3000)
     o.step(3000)
-    check(g, o, "sheba melt season +3000", rtol=1e-5)
+    check(g, o, "sheba melt season +3000")
 
 
 def test_launch_granularity_does_not_change_results():
@@ -455,23 +455,37 @@ def test_per_column_ocean_grid_of_columns():
     g, o = pair(cfg, ncol, st, forcing=sheba_forcing())
     for s in (g, o):
         s.set_ocean(dq, sb)
-    # free run through open water and the first days of ice (day 64), then windows restarted from the checker's state every four
-    # days up to day 100: freeze-up with first snow amplifies round-off in a free run, a window does not
+    # Free run through open water and the first ice (day 64), then ONE-DAY windows restarted from the checker's state every second
+    # day up to day 100.  Why windows: two events of the freeze-up amplify round-off -- the first ice layer (day 64-65) and the
+    # first, thinner-than-thick_min snow on three to five layers of ice (day 66-67, the thin-snow coupling's fixed-size enthalpy
+    # steps).  profiles/r3_freeze_up_sensitivity*.json shows it without any GPU: the checker against its own -ffp-contract=fast
+    # build, same 64 columns, parts by up to 3e-4 in 10 columns exactly there in a free run (which is what round 2's free run to
+    # day 75 had met: 4e-5), and stays below 3e-13 on every one-day window from day 68 on (profiles/r3_freeze_up_windows_1day.json).
+    # So: the two windows that hold the events at the parity bar, every later one at 1e-9 like the main path's reference windows.
     n = 8641 * 64
     g.step(n)
     o.step(n)
     sg, so = check(g, o, "ocean grid, day 64")
     assert np.array_equal(sg.sc("S_bu_bottom"), sb)
     spread = set()
-    while o.get_clock().step < 8641 * 100:
+    worst_late = 0.0
+    for day in range(64, 100, 2):
         k = o.get_clock()
+        assert k.step == 8641 * day
         g.set_state(o.get_state())
         g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
-        g.step(1500)
-        o.step(1500)
-        sg, so = check(g, o, f"ocean grid, window at step {k.step}")
+        g.step(8641)
+        o.step(8641)
+        sg, so = check(g, o, f"ocean grid, day {day} -> {day + 1}")
         spread.update(int(v) for v in so.n_active)
-        o.step(8641 * 4 - 1500)
+        if day >= 68:
+            kk = np.arange(sg.nlayer)[:, None] < so.n_active[None, :]
+            for name in ("H_abs", "S_abs", "m", "thick", "T"):
+                floor = 1e-3 if name == "H_abs" else 1e-9
+                worst_late = max(worst_late, rel_err(sg.arr(name)[kk], so.arr(name)[kk], floor))
+        o.step(8641)
+    print(f"ocean grid: worst one-day window from day 68 on {worst_late:.2e}")
+    assert worst_late <= 1e-9
     assert len(spread) > 8                                                  # the oceans spread the ensemble
     assert abs(float(sg.sc("fl_q_bottom")[5] - sg.sc("fl_q_bottom")[0]) - dq[5]) < 1e-12
     # column 0 (no offset, cfg.S_bu_bottom) is the single-ocean column, bit for bit

@@ -74,6 +74,51 @@ def test_sheba_windows_started_from_the_reference_records():
     assert worst <= 1e-9   # observed <= 1e-11: far inside the bar
 
 
+def test_sheba_free_run_from_open_water_against_the_reference_records():
+    """cfg3 as SURVEY.md section 8(d) words it: the unperturbed SHEBA column FREE from open water -- no restart from anybody's state
+    in between -- through freeze-up, first snow and the growth season to day 300 (2.6 million steps), every output day against the
+    flang-built reference's own record of that day: the scalars of all 300 days (tc4_ref_fullprec.npz all_s_*), the layer arrays on
+    the days the fixture holds them (day_index).  The reference's -O2 and FMA builds stay within 2e-12 of each other over this
+    span; the first melt season (day 347 on) is where free runs part, and is covered by the windows above."""
+    ref = golden("tc4_ref_fullprec.npz")
+    cfg, st = tcs.testcase4(1)
+    g = samsim_amd.hip_solver(cfg, 1)
+    g.set_forcing(*sheba_forcing())
+    g.set_state(st)
+    g.set_clock()
+    g.set_output_window(0, 1)
+    layer_days = {int(d): j for j, d in enumerate(ref["day_index"])}      # output number (1-based) -> row of the a_* block
+    last, worst, worst_at = 301, 0.0, None
+    scalars = (("thickness", 1e-7), ("bulk_salin", 1e-7), ("freeboard", 1e-7), ("energy_stored", 1e-3), ("freshwater", 1e-7),
+               ("total_resist", 1e-7), ("m_snow", 1e-5), ("thick_snow", 1e-7), ("H_abs_snow", 1.0), ("T_snow", 1e-2), ("T_top", 1e-2),
+               ("T2m", 1e-2), ("fl_q_bottom", 1e-7), ("albedo", 1e-7), ("fl_sw", 1e-7), ("fl_lw", 1e-7), ("grav_drain", 1e-12),
+               ("grav_salt", 1e-9), ("grav_temp", 1e-6), ("melt_out1", 1e-9), ("melt_out2", 1e-9), ("melt_out3", 1e-9))
+    seen_layers = 0
+    for i in range(last):                                                  # output i is the reference's output day i (0-based)
+        out = g.run_to_output()
+        assert out.step == ref["all_step"][i], (i, out.step, ref["all_step"][i])
+        assert out.n_active[0] == ref["all_N_active"][i], f"output {i}: N_active {out.n_active[0]} vs {ref['all_N_active'][i]}"
+        for n, floor in scalars:
+            e = rel_err(out.sc(n)[0], ref["all_s_" + n][i], floor)
+            if e > worst:
+                worst, worst_at = e, (i, n)
+            assert e <= RTOL, f"free run, output day {i}: {n} = {out.sc(n)[0]!r} vs the reference's {ref['all_s_' + n][i]!r} ({e:.2e})"
+        if i + 1 in layer_days:
+            j, na = layer_days[i + 1], int(out.n_active[0])
+            seen_layers += 1
+            for n in ["T", "psi_s", "psi_l", "psi_g", "S_bu", "thick", "H_abs", "S_abs", "m", "ray"]:
+                floor = {"H_abs": 1e-3, "psi_g": 1e-6, "ray": 1e-6}.get(n, 1e-9)
+                hi = na - 1 if n == "ray" else na
+                e = rel_err(out.arr(n)[:hi, 0], ref["a_" + n][j, :hi], floor)
+                if e > worst:
+                    worst, worst_at = e, (i, n)
+                assert e <= RTOL, f"free run, output day {i}: layers of {n} rel err {e:.2e} vs the reference record"
+    assert not g.get_status()[0].any()
+    assert seen_layers >= 15 and out.n_active[0] == 100                    # layer records through freeze-up and growth were compared
+    print(f"free run to output day {last - 1}: worst relative deviation from the reference's records {worst:.2e} at {worst_at}")
+    assert worst <= 1e-8   # (the bar is 1e-6; a free run that stays this close did not meet an amplifying event)
+
+
 def test_cfg2_full_run_65536_columns_against_all_72_reference_records():
     ref = golden("tc1_ref_fullprec.npz")
     ncol = 65536

@@ -139,16 +139,15 @@ def bench_scalar_index(name):
     return list(SCALARS).index(name)
 
 
-def test_a_step_split_over_two_streams_equals_the_single_launch(monkeypatch):
+def test_a_step_split_over_two_streams_equals_the_single_launch():
     """A step of a large ensemble (>= 8 192 column blocks) is two launches on two streams, half of the blocks each; here the
-    threshold is lowered so that a 1 000-column ensemble splits.  Several steps back to back (no wait in between), output
+    threshold is lowered (samsim_set_launch_split) so that a 1 000-column ensemble splits.  Several steps back to back (no wait in between), output
     snapshot and status included, must equal the unsplit run bit for bit."""
     import samsim_amd
     from tests.shard_worker import ensemble_shard
     results = []
-    for split in ("0", "2"):
-        monkeypatch.setenv("SAMSIM_SPLIT_BLOCKS", split)
-        st, status = ensemble_shard(0, 1000, 260, launches=4)
+    for split in (0, 2):
+        st, status = ensemble_shard(0, 1000, 260, launches=4, split_blocks=split)
         results.append((st, status))
     (a, xa), (b, xb) = results
     assert np.array_equal(xa, xb) and not xa.any()

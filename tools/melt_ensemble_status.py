@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """One-off GPU record for profiles/: a free-running perturbed SHEBA ensemble through the melt season and the following
 freeze-up -- the regime where the fused down sweep decides per step whether the volume-fraction rows are stored (sweep_down_fused)
-and the late readers (melt film, func_freeboard, flush3) assert that they were (library code 9001).  Every column gets its own
-T2m / precipitation perturbation (counter-based, global column id); the states tile the 256-member day-345 fixture.
+and the late readers (melt film, func_freeboard, flush3) rely on it (refill_psi_rows is their safety net).  Every column gets its own
+T2m / precipitation perturbation (counter-based, global column id); the states tile the 256-member day-345 fixture.  Run on the
+counter build of the library (-DSAMSIM_STAMPS=2) the record also holds how often the safety net ran.
 
-    python tools/melt_ensemble_status.py --ncol 4096 --days 115 > profiles/r2_melt_ensemble_status.json
+    SAMSIM_HIP_LIB=samsim_amd/csrc/variants/libsamsim_hip_st2.so python tools/melt_ensemble_status.py --ncol 4096 --days 115 > profiles/r3_melt_ensemble_status.json
 """
 import argparse
 import json
@@ -35,6 +36,12 @@ def main():
     bench.upload_tiled(g, st, a.ncol, 0)
     g.set_clock(**clock)
     g.set_output_window(0, 0)
+    lib = samsim_amd.load()
+    counters = hasattr(lib, "samsim_debug_stamps")
+    if counters:
+        import ctypes as C
+        buf = (C.c_ulonglong * 48)()
+        assert lib.samsim_debug_stamps(buf, 1) == 0
     t0 = time.time()
     rows = []
     for d in range(a.days):
@@ -51,7 +58,9 @@ def main():
     status = g.get_status()[0]
     out = {"what": "free-running perturbed SHEBA ensemble through melt season and freeze-up (sweep_down_fused's stored-row decision)",
            "ncol": a.ncol, "nlayer": int(cfg.nlayer), "fixture": a.fixture, "days": a.days, "steps": a.days * 8640,
-           "columns_with_code_9001": int((status == 9001).sum()), "columns_stopped": int((status != 0).sum()),
+           "columns_stopped": int((status != 0).sum()),
+           "refill_psi_rows_lane_calls": (int(buf[32]) if counters and lib.samsim_debug_stamps(buf, 0) == 0 else None),
+           "flush3_lane_calls": (int(buf[29]) if counters else None), "freeboard_lane_calls": (int(buf[31]) if counters else None),
            "lib_md5": bench.lib_md5(), "rows": rows}
     print(json.dumps(out, indent=1))
 

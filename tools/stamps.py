@@ -19,7 +19,8 @@ import bench  # noqa: E402
 NAMES = ["t_prologue", "t_down_fused", "t_down_unfused", "t_surface", "t_up", "t_post", "t_head", "t_tail",
          "wave_steps", "fused", "unfused", "up_trips", "newton_wave", "newton_lane", "lanes", "down_trips", "drain_wave",
          "drain_lane", "dirty", "lanes_coupling", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC",
-         "lanes_flood_possible", "lanes_irregular", "lanes_dirty", "lanes_unfused", "lanes_flush3", "lanes_regrid", "lanes_freeboard"]
+         "lanes_flood_possible", "lanes_irregular", "lanes_dirty", "lanes_unfused", "lanes_flush3", "lanes_regrid", "lanes_freeboard",
+         "lanes_refill_psi"] + [f"slot{i}" for i in range(33, 48)]
 
 
 def main():
@@ -43,7 +44,7 @@ def main():
     g.set_clock(**clock)
     g.set_output_window(0, 0)
     lib = samsim_amd.load()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 48)()
     g.step(args.substeps)
     g.synchronize()
     assert lib.samsim_debug_stamps(buf, 1) == 0
