@@ -38,9 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-# CPU port vs the reference itself (flang -O2, one Xeon core of the build container, testcase 4 from open water,
-# first 3.0e6 steps): oracle 2.32e4 column-timesteps/s, reference 2.58e4
-CALIBRATION_VS_FLANG = 0.90
+# CPU port vs the reference itself as measured ONCE in the build container (flang -O2, one Xeon core, testcase 4 from open water,
+# first 3.0e6 steps: oracle 2.32e4 column-timesteps/s, reference 2.58e4).  Only quoted when the reference binary is absent: the
+# cpu_baseline leg times the reference itself in the same run (cpu_reference below) and derives the factor from that.
+CALIBRATION_VS_FLANG_BUILD_CONTAINER = 0.90
+REF_BINARY = os.path.join(ROOT, "oracle", "_ref", "samsim_ref_dump")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -130,7 +132,56 @@ def host_cores():
     return n, src
 
 
-def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
+def cpu_reference(nsteps):
+    """The reference itself on one host core: oracle/_ref/samsim_ref_dump -- the unmodified reference physics (mo_grotz and the
+    modules it calls, SAMSIM.f90:84-106 entry restated by oracle/ref_hook/ref_driver.f90) built by oracle/build_ref.sh with flang
+    -O2, statically linked, writer module replaced by a hook that here writes nothing (SAMSIM_REF_QUIET) -- run as a CHILD process
+    on testcase 4 from open water for `nsteps` steps in a scratch directory holding the four forcing tables, next to the port on
+    exactly that run (one column, one thread).  The reference has no restart, so it cannot start from the bench's spun-up
+    ensemble: the ratio of the two on the same run is what carries the port's rate on the bench workload over to the reference."""
+    import shutil
+    import tempfile
+    from samsim_amd import testcases as tcs
+    from tests.oracle_lib import oracle_solver
+    if not os.path.exists(REF_BINARY):
+        return None, f"{os.path.relpath(REF_BINARY, ROOT)} absent (built by oracle/build_ref.sh where /root/reference exists)"
+    f = sheba_forcing()
+    d = tempfile.mkdtemp(prefix="samsim_ref_")
+    try:
+        os.mkdir(os.path.join(d, "output"))
+        for name, a in zip(("flux_sw", "flux_lw", "T2m", "precip"), f):
+            np.savetxt(os.path.join(d, name + ".txt.input"), a, fmt="%.17e")      # sub_input, mo_functions.f90:304-327: list-directed reads
+        env = dict(os.environ, SAMSIM_REF_QUIET="1", SAMSIM_REF_MAXSTEPS=str(nsteps), OMP_NUM_THREADS="1")
+        # the child runs on a core of its own while this process times the port on another (both single-threaded); the child's
+        # time is its own CPU time (user + system, os.wait4), which for a compute-bound process is its run time
+        child = subprocess.Popen([REF_BINARY, "4"], cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cfg, st = tcs.testcase4(1)
+        o = oracle_solver(cfg, 1)
+        o.set_threads(1)
+        o.set_forcing(*f)
+        o.set_state(st)
+        o.set_clock()
+        t = time.perf_counter()
+        o.step(nsteps)
+        t_port = time.perf_counter() - t
+        na = int(o.get_state().n_active[0])
+        o.close()
+        _, status, ru = os.wait4(child.pid, 0)
+        child.returncode = os.waitstatus_to_exitcode(status)
+        t_ref = ru.ru_utime + ru.ru_stime
+        if child.returncode != 0:
+            return None, f"samsim_ref_dump exited with {child.returncode}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return {"value": nsteps / t_ref, "unit": "column-timesteps/s", "cores": 1, "kind": "reference",
+            "sample": f"testcase 4 (Nlayer 100) from open water, first {nsteps} steps of one column (N_active reaches {na}), "
+                      f"flang -O2 build of the unmodified reference physics as a child process: {t_ref:.1f} s of CPU time; the port on "
+                      f"the same run, one thread, at the same time on another core: {t_port:.1f} s",
+            "seconds": t_ref, "port_on_the_same_run": {"value": nsteps / t_port, "seconds": t_port},
+            "port_over_reference": (nsteps / t_port) / (nsteps / t_ref)}, None
+
+
+def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s, ref_steps):
     """oracle (C port of the reference algorithm) on a bounded sample of the same workload: all cores of this process's
     affinity mask (columns over OpenMP threads), then one core"""
     from samsim_amd.capi import State
@@ -156,15 +207,27 @@ def cpu_baseline(cfg, st, pert, clock, forcing, col0, target_s):
     cores, cores_source = host_cores()
     v_all, n_all, t_all = run(cores, 4 * cores, target_s)
     v_one, n_one, t_one = run(1, 4, 0.5 * target_s)
-    return {"value": v_all, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
-            "sample": f"{4 * cores} columns x {n_all} steps of the same workload on {cores} OpenMP threads ({t_all:.1f} s); "
-                      f"one core: 4 columns x {n_one} steps ({t_one:.1f} s)",
-            "cores_source": cores_source,
-            "one_core": {"value": v_one, "unit": "column-timesteps/s", "cores": 1},
-            "parallel_speedup_measured": v_all / v_one,
-            "calibration_vs_flang": CALIBRATION_VS_FLANG,
-            "calibration_note": "this port runs at 0.90x the flang -O2 build of the reference itself (same core, testcase 4, "
-                                "first 3.0e6 steps; DESIGN.md section 6)"}
+    out = {"value": v_all, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
+           "sample": f"{4 * cores} columns x {n_all} steps of the same workload on {cores} OpenMP threads ({t_all:.1f} s); "
+                     f"one core: 4 columns x {n_one} steps ({t_one:.1f} s)",
+           "cores_source": cores_source,
+           "one_core": {"value": v_one, "unit": "column-timesteps/s", "cores": 1},
+           "parallel_speedup_measured": v_all / v_one}
+    ref, why_not = (None, "skipped (--ref-steps 0)") if ref_steps <= 0 or forcing is None else cpu_reference(ref_steps)
+    if ref is not None:
+        out["reference"] = ref
+        out["calibration_vs_flang"] = ref["port_over_reference"]
+        out["calibration_note"] = ("measured in this run, on this host: the port's rate over the reference's on testcase 4 from open "
+                                   "water (cpu_baseline.reference); the reference cannot start from the bench's spun-up ensemble")
+        out["reference_equivalent_on_this_workload"] = {"one_core": v_one / ref["port_over_reference"],
+                                                       "all_cores": v_all / ref["port_over_reference"], "unit": "column-timesteps/s",
+                                                       "how": "port on the bench workload / (port / reference on the common run)"}
+    else:
+        out["reference"] = {"skipped": why_not}
+        out["calibration_vs_flang"] = CALIBRATION_VS_FLANG_BUILD_CONTAINER
+        out["calibration_note"] = ("constant from the build container (one Xeon core, testcase 4, first 3.0e6 steps): the reference "
+                                   "binary was not timed in this run")
+    return out
 
 
 def lib_md5():
@@ -202,10 +265,45 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # all children are watched together: when one rank dies (HIP error, missing fixture, the rendezvous port taken in the gap
+    # between the probe above and the ranks' bind) its siblings would sit in the gloo barrier until its timeout -- they are ended
+    # and the first failure is what this process returns
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
+
+
+def shared_devices(ranks):
+    """[(pci bus id, [ranks])] for every GPU more than one rank ran on"""
+    by = {}
+    for r in ranks:
+        by.setdefault(r["pci_bus_id"], []).append(r["rank"])
+    return [[k, v] for k, v in sorted(by.items()) if len(v) > 1]
+
+
+def gather_ranks(dist, world, rank, mine):
+    """every rank's record (a small dict) on rank 0, over the gloo group the barrier uses"""
+    if dist is None:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
 
 
 def timed_window(g, substeps, launches, warmup, barrier):
@@ -275,6 +373,9 @@ def main():
     ap.add_argument("--sites", type=int, default=1,
                     help="forcing sets (samsim_set_forcing_sites): the tables replicated N times, column c on set c mod N")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--ref-steps", type=int, default=1500000,
+                    help="cpu_baseline: steps of testcase 4 from open water on which the reference binary and the port are timed "
+                         "side by side (0 = skip; about half a minute, both at once, at the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the stage windows (open water ... melt season)")
     ap.add_argument("--extra-launches", type=int, default=2)
@@ -307,7 +408,8 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -325,7 +427,9 @@ def main():
             dist.barrier()
             shards = t.tolist()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "shards_rank_device_col0_ncol": shards}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "shards_rank_device_col0_ncol": shards,
+                              "shared_devices": shared_devices([dict(rank=r, device=d, pci_bus_id=f"dry-run:{d}") for r, d, _, _ in shards])}),
+                  flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -352,6 +456,13 @@ def main():
 
     wall, kernel_ms, cells, nfail = timed_window(g, args.substeps, args.steps, args.warmup, barrier)
 
+    # who ran where: every rank reports the device its handle lives on (ordinal and PCI bus id, from the library), its column range
+    # and its own rate; rank 0 prints them and refuses a record in which two ranks shared a GPU unless that was asked for
+    dev_ordinal, pci = g.get_device()
+    ranks = gather_ranks(dist, world, rank, {"rank": rank, "local_rank": local_rank, "device": dev_ordinal, "pci_bus_id": pci,
+                                             "host": socket.gethostname(), "col0": col0, "ncol": ncol,
+                                             "column_timesteps_per_s": ncol * args.steps * args.substeps / wall,
+                                             "mean_launch_ms": float(np.mean(kernel_ms)), "failed_columns": nfail})
     wall_max, fails = wall, float(nfail)
     if dist is not None:
         import torch
@@ -370,13 +481,17 @@ def main():
         mean_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_colstep * ncol * args.substeps / (mean_ms * 1e-3) / 1e9
         traffic, traffic_source = profiled_traffic(f"{args.workload}:{ncol}:{nlayer}:{args.substeps}")
+        shared = shared_devices(ranks)
+        if shared and args.device_map is None:
+            sys.exit(f"bench.py: ranks share a GPU without --device-map: {shared} (ranks: {ranks})")
         out = {
             "metric": "column-timesteps/sec", "value": value, "unit": "column-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
             "config": {"workload": wname, "ncol_per_gpu": ncol, "nlayer": nlayer, "timesteps_per_step": args.substeps,
                        "timed_timesteps": timesteps,
-                       "parallelism": f"columns sharded over {world} GPU(s), no collective", "forcing_sites": args.sites},
+                       "parallelism": f"columns sharded over {world} GPU(s), no collective", "forcing_sites": args.sites,
+                       "ranks": ranks, "shared_devices": shared, "per_gpu_mean": value / world},
             "layer_cell_updates_per_s": cells / wall_max,
             "failed_columns": int(fails),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -397,7 +512,7 @@ def main():
                                                "how": "time-weighted over the stage windows day 0 / 75 / 150 / 200 (headline) / 250 / 300; "
                                                       "each stage stands for the days around it"}}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, st, pert, clock, forcing, col0, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, st, pert, clock, forcing, col0, args.cpu_seconds, args.ref_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,7 +18,7 @@ MODULE mo_data
   IMPLICIT NONE
   INTEGER, PARAMETER :: wp = SELECTED_REAL_KIND(12, 307)   ! mo_parameters.f90:33
   REAL(wp), PARAMETER :: rho_l = 1028.0_wp, c_l = 3400._wp, k_s = 2.2_wp, rho_s = 920._wp, c_s = 2020.0_wp
-  INTEGER(c_int64_t), PARAMETER :: restart_magic = INT(z'31304B48434D4153', c_int64_t)   ! the bytes "SAMCHK01"
+  INTEGER(c_int64_t), PARAMETER :: restart_magic = INT(z'32304B48434D4153', c_int64_t)   ! the bytes "SAMCHK02" (chunks carry the status block)
   REAL(wp), PARAMETER :: sigma = 5.6704_wp*1e-8   !< Stefan Boltzmann constant as written in mo_parameters.f90:59
 
   TYPE(samsim_config) :: cfg                 !< every flag / scalar that crosses the C-ABI

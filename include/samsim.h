@@ -182,6 +182,9 @@ int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms);
  * head of the next), and the device time of the whole sequence, measured with HIP events on the handle's streams (ABI 4) */
 int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, double *device_ms);
 int samsim_synchronize(samsim_handle *h);
+/* which GPU the handle lives on: the ordinal passed to samsim_create and the PCI bus id HIP reports for it (pci_bus_id: buffer
+ * of len >= 16 bytes, or NULL).  A multi-process run records it per rank so that a scaling record shows no GPU was shared.  ABI 5. */
+int samsim_get_device(samsim_handle *h, int32_t *device, char *pci_bus_id, int32_t len);
 /* How a step of a large ensemble is launched (no reference counterpart; results do not depend on it, bit for bit).  From
  * min_blocks 64-column blocks up (default 8 192 = 524 288 columns; 0 = never) a step runs as two concurrent launches on the
  * handle's two HIP streams, the first taking first_part_eighths/8 of the blocks (default 4): the workgroups of one launch finish

@@ -2048,6 +2048,8 @@ int oracle_set_ocean(oracle_handle *h, const double *dfl_q_bottom_col, const dou
   if (!h) return SAMSIM_ERR_ARG;
   if (dfl_q_bottom_col && h->cfg.testcase != 4 && h->cfg.testcase != 7) return SAMSIM_ERR_UNSUPPORTED;
   if (S_bu_bottom_col && h->cfg.tank_flag == 2) return SAMSIM_ERR_UNSUPPORTED;
+  for (int64_t i = 0; S_bu_bottom_col && i < h->ncol; i++)   /* as samsim_set_ocean: nothing is changed by a rejected call */
+    if (!(S_bu_bottom_col[i] >= 0.0)) return SAMSIM_ERR_ARG;
   for (int64_t i = 0; i < h->ncol; i++) {
     column *c = &h->cols[i];
     c->dflq = dfl_q_bottom_col ? dfl_q_bottom_col[i] : 0.0;

@@ -214,6 +214,8 @@ class Solver:
         f.argtypes, f.restype = [vp, i64, C.c_int32, C.POINTER(C.c_double)], C.c_int
         f = self._f("synchronize")
         f.argtypes, f.restype = [vp], C.c_int
+        f = self._f("get_device")
+        f.argtypes, f.restype = [vp, C.POINTER(C.c_int32), C.c_char_p, C.c_int32], C.c_int
         f = self._f("set_launch_split")
         f.argtypes, f.restype = [vp, i64, C.c_int32], C.c_int
 
@@ -288,6 +290,12 @@ class Solver:
 
     def synchronize(self):
         self._chk(self._f("synchronize")(self._h), "synchronize")
+
+    def get_device(self):
+        """(HIP device ordinal, PCI bus id) of the GPU this handle lives on"""
+        dev, buf = C.c_int32(-1), C.create_string_buffer(32)
+        self._chk(self._f("get_device")(self._h, C.byref(dev), buf, 32), "get_device")
+        return int(dev.value), buf.value.decode()
 
     def set_launch_split(self, min_blocks: int = 8192, first_part_eighths: int = 4):
         """from how many 64-column blocks a step runs as two concurrent launches (0 = never), and the first part's share"""

@@ -3,11 +3,12 @@ run there always starts from `init(testcase)`).
 
 The file is a little-endian stream that the Fortran host reads and writes as well (host/host_driver.f90, ACCESS='stream'):
 
-    header   int64 magic "SAMCHK01", ncol, nlayer, narr, nscal, testcase,
+    header   int64 magic "SAMCHK02", ncol, nlayer, narr, nscal, testcase,
              float64 time, int64 step, n_time_out, time_counter, n_outputs, int64 n_bgc, int64 has_status, int64 reserved[3]
     chunks   int64 col0, ncols, then lay[narr][nlayer][ncols], scal[nscal][ncols] (float64), n_active[ncols] (int32),
-             with has_status = 1 (every file written by this version) status[ncols], err_layer[ncols] (int32) and
-             err_step[ncols] (int64): the STOP code of a frozen column and where it failed (samsim_get_status),
+             status[ncols], err_layer[ncols] (int32) and err_step[ncols] (int64): the STOP code of a frozen column and where
+             it failed (samsim_get_status; has_status = 1 in every "SAMCHK02" file -- the chunk layout without them was
+             "SAMCHK01", which this version refuses by its magic instead of mis-reading it),
              and with tracers (n_bgc > 0) bgc_abs[n_bgc][nlayer][ncols], bgc_bottom[n_bgc][ncols] (float64)
              ... until ncol columns are covered
 
@@ -25,7 +26,8 @@ import numpy as np
 
 from .capi import NARR, NPROG, NSCAL, Solver, State
 
-MAGIC = int.from_bytes(b"SAMCHK01", "little")
+MAGIC = int.from_bytes(b"SAMCHK02", "little")
+MAGIC_OLD = int.from_bytes(b"SAMCHK01", "little")   # chunks without the status block: refused
 _HDR = struct.Struct("<6q d 4q 5q")
 
 
@@ -59,6 +61,8 @@ def save(solver: Solver, path: str, narr: int = NARR, chunk: int = 65536) -> Non
 def read_header(path: str) -> dict:
     with open(path, "rb") as f:
         v = _HDR.unpack(f.read(_HDR.size))
+    if v[0] == MAGIC_OLD:
+        raise ValueError(f"{path}: checkpoint layout SAMCHK01 (no status block per chunk) is not read by this version")
     if v[0] != MAGIC:
         raise ValueError(f"{path}: not a SAMSIM checkpoint")
     return dict(ncol=v[1], nlayer=v[2], narr=v[3], nscal=v[4], testcase=v[5], time=v[6], step=v[7], n_time_out=v[8],

@@ -461,19 +461,21 @@ int samsim_set_ocean(samsim_handle *h, const double *dfl_q_bottom_col, const dou
   // the offset rides on the flux sub_test4 sets every step; the salinity replaces cfg.S_bu_bottom, which the tank budget owns with tank_flag 2
   if (dfl_q_bottom_col && h->cfg.testcase != 4 && h->cfg.testcase != 7) return SAMSIM_ERR_UNSUPPORTED;
   if (S_bu_bottom_col && h->cfg.tank_flag == 2) return SAMSIM_ERR_UNSUPPORTED;
-  HIPCHK(hipStreamSynchronize(h->stream));
   const size_t nc = (size_t)h->ncol;
+  for (size_t i = 0; S_bu_bottom_col && i < nc; ++i) if (!(S_bu_bottom_col[i] >= 0.0)) return SAMSIM_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // the new arrays are complete on the device before the handle sees them: a call that fails leaves the handle as it was
+  double *dq = nullptr, *sb = nullptr;
+  bool ok = true;
+  if (dfl_q_bottom_col)
+    ok = hip_ok(dalloc(&dq, nc), "hipMalloc ocean_dflq") &&
+         hip_ok(hipMemcpy(dq, dfl_q_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice), "hipMemcpy ocean_dflq");
+  if (ok && S_bu_bottom_col)
+    ok = hip_ok(dalloc(&sb, nc), "hipMalloc ocean_sbu") &&
+         hip_ok(hipMemcpy(sb, S_bu_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice), "hipMemcpy ocean_sbu");
+  if (!ok) { (void)hipFree(dq); (void)hipFree(sb); return SAMSIM_ERR_HIP; }
   (void)hipFree(h->ocean_dflq); (void)hipFree(h->ocean_sbu);
-  h->ocean_dflq = h->ocean_sbu = nullptr;
-  if (dfl_q_bottom_col) {
-    HIPCHK(dalloc(&h->ocean_dflq, nc));
-    HIPCHK(hipMemcpy(h->ocean_dflq, dfl_q_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice));
-  }
-  if (S_bu_bottom_col) {
-    for (size_t i = 0; i < nc; ++i) if (!(S_bu_bottom_col[i] >= 0.0)) return SAMSIM_ERR_ARG;
-    HIPCHK(dalloc(&h->ocean_sbu, nc));
-    HIPCHK(hipMemcpy(h->ocean_sbu, S_bu_bottom_col, sizeof(double) * nc, hipMemcpyHostToDevice));
-  }
+  h->ocean_dflq = dq; h->ocean_sbu = sb;
   return SAMSIM_OK;
 }
 
@@ -591,6 +593,13 @@ int samsim_steps_timed(samsim_handle *h, int64_t nsteps, int32_t nlaunches, doub
 }
 
 int samsim_step_timed(samsim_handle *h, int64_t nsteps, double *kernel_ms) { return samsim_steps_timed(h, nsteps, 1, kernel_ms); }
+
+int samsim_get_device(samsim_handle *h, int32_t *device, char *pci_bus_id, int32_t len) {
+  if (!h) return SAMSIM_ERR_ARG;
+  if (device) *device = h->device;
+  if (pci_bus_id && len > 0) HIPCHK(hipDeviceGetPCIBusId(pci_bus_id, len, h->device));
+  return SAMSIM_OK;
+}
 
 int samsim_set_launch_split(samsim_handle *h, int64_t min_blocks, int32_t first_part_eighths) {
   int rc = use(h);

@@ -36,6 +36,8 @@ enum dev_spec {
   SP_MINP = 0, SP_STP, SP_ST,               // suffix min(perm), sum(thick/perm), sum(thick) over layers 2..N_active-1
   SP_BOT, SP_BOTTERM, SP_PERM_BOT, SP_SBR_BOT,  // bottom-layer terms of the Rayleigh number
   SP_BUOY_S, SP_MIN_PSI_S,                  // partial SUM(psi_s*thick), MIN(psi_s) over layers 2..N_active
+  // from the down sweep of a step to func_freeboard later in the same step (written where the sweep stores the volume-fraction rows):
+  SP_FB_A2, SP_FB_G2,                       // SUM(psi_s*thick), SUM(psi_g*thick) over layers 2..N_active, top -> bottom
   DEV_NSPEC
 };
 

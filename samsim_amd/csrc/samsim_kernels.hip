@@ -374,40 +374,38 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
   ddT_f = c_s + c_s_beta * T_0 - latent_heat * S_bu * ddT_S_br(s, T_0) / dmax(sb * sb, 0.0000000001);
 }
 
-// SAMSIM_NEWTON1: one division per Newton step of getT instead of two.  With f = N/sb**2 and f' = D/sb**2 (N = A*sb**2 +
-// L*S_bu*sb, D = B*sb**2 - L*S_bu*S_br'(T), A and B the polynomial parts) the step is T_0 - N/D and the stopping rule |f| > 1 reads
-// |N| > sb**2: the same iteration in exact arithmetic, each iterate within an ulp or two of the reference's (like the shared
-// reciprocals above), 8 fewer instructions and 8 fewer links in the dependent chain per evaluation -- and getT runs 3.6
-// evaluations per layer-cell on the bench ensemble, all of them on the critical path of the up sweep.  Only taken where the
-// reference's clamps of S_br (1e-9 / 1e-10) are inactive (sb > 1e-4); 0 = two divisions.
-// SAMSIM_CLAMP_MAX: the clamps of the liquidus and of Expulsion as single v_max_f64
-// one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1
-__device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
-  // the same step with fused multiply-adds (one rounding per a*b+c instead of two: 27 vector instructions instead of 41 per
-  // evaluation, 3.6 evaluations per layer-cell, all on the critical path of the up sweep); each iterate within an ulp or two
-  // of the unfused form's, like the other ulp-level changes of this file
+// One division per Newton step of getT instead of two: with f = N/sb**2 and f' = D/sb**2 (N = A*sb**2 + L*S_bu*sb, D = B*sb**2 -
+// L*S_bu*S_br'(T), A and B the polynomial parts) the step is T_0 - N/D and the stopping rule |f| > 1 reads |N| > sb**2: the same
+// iteration in exact arithmetic.  getT runs 3.6 evaluations per layer-cell on the bench ensemble, all of them on the critical path
+// of the up sweep.
+// One evaluation of the Newton step of getT from T_0 in the one-division form, with fused multiply-adds (one rounding per a*b+c
+// instead of two; each iterate within an ulp or two of the reference's, like the shared reciprocals): T_new = T_0 - N/D, more =
+// |N| > sb**2 (the reference's |f| > 1), ok = the liquidus salinity at T_0 is above 1e-4, i.e. the reference's clamps of S_br
+// (1e-9 / 1e-10) are inactive and this form is the step.  A0 = -latent_heat - H and LS = latent_heat * S_bu are the caller's
+// (the same for every evaluation of a layer).  Straight-line: no branch, 23 vector instructions.
+__device__ __forceinline__ void newton_eval(const Salt &s, double A0, double LS, double T_0, double &T_new, bool &more, bool &ok) {
   const double sbf = T_0 * __builtin_fma(T_0, __builtin_fma(T_0, s.c4, s.c3), s.c2);
-  if (sbf > 0.0001) {
-    const double sb2 = sbf * sbf, LS = latent_heat * S_bu;
-    const double A = __builtin_fma(T_0, __builtin_fma(T_0, 0.5 * c_s_beta, c_s), -latent_heat - H);
-    const double B = __builtin_fma(c_s_beta, T_0, c_s);
-    const double num = __builtin_fma(A, sb2, LS * sbf);
-    const double Tc = T_0 < -20.0 ? -20.0 : T_0;
-    const double dd = __builtin_fma(Tc, __builtin_fma(Tc, 3.0 * s.d4, 2.0 * s.d3), s.d2);
-    const double den = __builtin_fma(B, sb2, -(LS * dd));
-    T_new = T_0 - quot(num, den);
-    return fabs(num) > sb2;
+  const double sb2 = sbf * sbf;
+  const double A = __builtin_fma(T_0, __builtin_fma(T_0, 0.5 * c_s_beta, c_s), A0);
+  const double B = __builtin_fma(c_s_beta, T_0, c_s);
+  const double num = __builtin_fma(A, sb2, LS * sbf);
+  const double Tc = max_c(T_0, -20.0);                       // derivative-only clamp below -20 C, mo_thermo_functions.f90:408-412
+  const double dd = __builtin_fma(Tc, __builtin_fma(Tc, 3.0 * s.d4, 2.0 * s.d3), s.d2);
+  const double den = __builtin_fma(B, sb2, -(LS * dd));
+  T_new = T_0 - quot(num, den);
+  more = fabs(num) > sb2;
+  ok = sbf > 0.0001;
+}
+
+// one Newton step from T_0: returns the new iterate and whether |f(T_0)| > 1 (general routine: any S_br)
+__device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu, double T_0, double sb_floor, double &T_new) {
+  {
+    bool more, ok;
+    double Tn;
+    newton_eval(s, -latent_heat - H, latent_heat * S_bu, T_0, Tn, more, ok);
+    if (ok) { T_new = Tn; return more; }
   }
   const double sb = S_br_poly(s, T_0);
-  if (sb > 0.0001) {
-    const double sb2 = sb * sb, LS = latent_heat * S_bu;
-    const double A = -latent_heat - H + c_s * T_0 + c_s_beta * T_0 * T_0 / 2.0;
-    const double B = c_s + c_s_beta * T_0;
-    const double num = A * sb2 + LS * sb;
-    const double den = B * sb2 - LS * ddT_S_br(s, T_0);
-    T_new = T_0 - quot(num, den);
-    return fabs(num) > sb2;
-  }
   double f, ddT_f;
   newton_terms(s, H, S_bu, T_0, sb, sb_floor, f, ddT_f);
   T_new = T_0 - quot(f, ddT_f);
@@ -464,11 +462,55 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
   return rc;
 }
 
+// getT for the layers of a sweep (the up sweeps, the full first sweep): the same iteration, arranged for a wave.  Winter columns
+// are mushy layers whose iterates stay inside (-200, 0) and whose liquidus salinity stays above 1e-4: for them getT is a first
+// evaluation and a loop of further ones, and every lane of the wave runs that loop together -- `while (some lane wants more)`, the
+// update selected per lane -- so that the loop is straight-line vector code under ONE scalar branch, without the exec-mask
+// bookkeeping of a per-lane `while` (a wave runs as many trips as its slowest lane either way: 3.57 against a lane mean of 3.33
+// in winter, 7.1 against 4.4 in the melt season).  A lane that is anything else -- fresh ice, pure brine, an iterate that leaves
+// the interval and needs T_fr, S_br under 1e-4, no convergence -- is redone by the general routine above, on its own: what a lane
+// gets depends on its own column only, and the arithmetic (newton_eval) is the general routine's.
+__device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out, int *evals = nullptr) {
+  const double Tl = T_liquid(H);
+  const bool mushy = S_br_clamped(s, Tl, S_bu) > S_bu && S_bu > 0.001;
+  const double A0 = -latent_heat - H, LS = latent_heat * S_bu;
+  double T;
+  bool more, ok;
+  newton_eval(s, A0, LS, T_in, T, more, ok);
+  bool odd = !mushy || !ok;
+  more = more && !odd;
+  int i = 0;
+  while (__ballot(more) != 0ull) {
+    double Tn;
+    bool m2, ok2;
+    newton_eval(s, A0, LS, T, Tn, m2, ok2);
+    if (more && (T > 0.0 || T < -200.0 || !ok2)) odd = true;     // (the test is on the iterate the evaluation started from)
+#if SAMSIM_STAMPS == 2
+    if (evals && more) *evals += 1;
+#endif
+    T = more ? Tn : T;
+    more = more && m2 && !odd;
+    if (++i == 260) { if (more) odd = true; break; }
+  }
+  double phi = 1.0 - quot(S_bu, S_br_clamped(s, T, S_bu));
+  int rc = 0;
+  if (odd) {
+    phi = phi_out;
+    rc = getT(s, H, S_bu, T_in, T, phi, evals);
+  }
+  T_out = T;
+  phi_out = phi;
+  return rc;
+}
+
 // The solid fraction getT returned for a layer, recomputed from the temperature it returned and the values it was called
 // with (mo_thermo_functions.f90:84,129,131-143): same operands, same operations, so the same phi bit for bit.  The down sweeps
 // use it instead of loading phi (one array less to hand over).
 __device__ __forceinline__ double phi_from_T(const Salt &s, double H, double S_bu, double S_br_T) {
-  if (S_br_clamped(s, T_liquid(H), S_bu) > S_bu && S_bu > 0.001) return 1.0 - quot(S_bu, S_br_T);
+  // S_bu > 0.001 is a mushy layer or pure brine.  getT gives pure brine phi = 0 and T = H/c_l, whose clamped liquidus salinity
+  // S_br_T is S_bu itself -- and quot(x, x) is exactly 1 (samsim_div.h: the residual correction removes what the rounded
+  // product x*r is off by) -- so the mushy layer's formula serves both and the liquidus need not be evaluated at H/c_l again.
+  if (S_bu > 0.001) return 1.0 - quot(S_bu, S_br_T);
   if (S_bu < 0.001) {
     if (H > 0.0) return 0.0;
     if (H <= -latent_heat) return 1.0;
@@ -563,7 +605,10 @@ struct Ctx {
   // Gravity drainage only reads ray(k) where it exceeds ray_crit (mo_grav_drain.f90:144), which in winter holds in two or three
   // of 80 layers: the up sweep stores a row only when some column of the wave is above the threshold in that layer (or when the
   // whole array is wanted: output, end of a launch), the down sweeps load only those rows and take 0 elsewhere.
-  lu64 *rflag;
+  // The words pass data between the lanes of the wave (the wave's first lane ORs a bit in, every lane reads it in the next step's
+  // down sweep): volatile, so that every access is an LDS instruction in program order -- one wave issues its LDS instructions
+  // in order and the LDS serves them in order -- and a wave barrier where the phases change (zeroing -> setting -> reading).
+  volatile lu64 *rflag;
   bool ray_rows_all;   // this up sweep stores every row
 
 #if SAMSIM_STAMPS
@@ -612,21 +657,15 @@ template <class K>
 __device__ RARE double func_freeboard(Col &c, const Ctx &x) {
   const int Na = c.Na;
   double snowmass = ((K::fixed ? K::freeboard_snow_flag : x.p->cfg.freeboard_snow_flag) == 0) ? CL(m_snow) : 0.0;
-  double A = 0.0, G = 0.0;
   THICK_RULE_INIT(tr);
-  // (rows are requested a chunk at a time -- see RARE_CHUNK -- and summed in the reference's order)
-  for (int k0 = 1; k0 <= Na; k0 += RARE_CHUNK) {
-    double th_[RARE_CHUNK], ps_[RARE_CHUNK], pg_[RARE_CHUNK];
-#pragma unroll
-    for (int i = 0; i < RARE_CHUNK; ++i) {
-      const int kk = (k0 + i <= c.N) ? k0 + i : c.N;
-      th_[i] = THICK_AT(tr, kk); ps_[i] = LAY(SAMSIM_A_PSI_S, kk); pg_[i] = LAY(SAMSIM_A_PSI_G, kk);
-    }
-#pragma unroll
-    for (int i = 0; i < RARE_CHUNK; ++i) {
-      if (k0 + i <= Na) { A += ps_[i] * th_[i]; G += pg_[i] * th_[i]; }
-    }
-  }
+  // The column totals SUM(psi_s*thick) and SUM(psi_g*thick): the sweep that stored the volume-fraction rows (sweep_down_fused,
+  // sweep_expulsion_transfer, refill_psi_rows) summed them over layers 2..N_active as it went, top -> bottom like the reference's
+  // SUM, and left the two sums in the hand-over block; layer 1 -- whose thickness snow slush, the melt film and melt water may have
+  // changed since -- is added here with what it holds now.  (Round 2 walked the whole column for them: two rows per layer-cell in
+  // every step of a melt season.)
+  const double th1 = LAY(SAMSIM_A_THICK, 1);
+  const double A = LAY(SAMSIM_A_PSI_S, 1) * th1 + ((Na >= 2) ? SPEC(SP_FB_A2) : 0.0);
+  const double G = LAY(SAMSIM_A_PSI_G, 1) * th1 + ((Na >= 2) ? SPEC(SP_FB_G2) : 0.0);
   double buoy = A * (rho_l - rho_s) + G * rho_l;
   double freeboard;
   if (snowmass > buoy) {
@@ -933,7 +972,7 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       ray = dmax(ray, 0.0);
       if (!sparse_rows) {
         LAYU(SAMSIM_A_RAY, k) = ray;
-      } else if (x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // the fused up sweep: wave-uniform k, see Ctx::rflag
+      } else if (k == 1 || x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // wave-uniform k, see Ctx::rflag (row 1 always: ray_row_valid)
         LAYU(SAMSIM_A_RAY, k) = ray;
         if (wave_leader()) x.rflag[(k - 1) >> 6] |= 1ull << ((k - 1) & 63);
       }
@@ -941,8 +980,12 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
   }
 }
 
+// all_phi: the solid fractions of every layer go to their array (an output point follows); otherwise only where something reads them
+// before the up sweep rewrites them (layer 1, the bottom two layers: thin-snow coupling, regrid trigger).  whole_wave: every column
+// of the wave runs this sweep (the normal state of a melt season, when every column flushes in every step): then the Rayleigh rows
+// are stored and flagged like the fused up sweep's -- only where some column drains -- instead of all of them.
 template <class K>
-__device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
+__device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x, bool all_phi, bool whole_wave) {
   const samsim_config &g = x.p->cfg;
   const Salt &s = x.salt;
   const int Na = c.Na;
@@ -951,7 +994,11 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
   RayScan r;
   ray_scan_init(r);
   int rc = 0, rc_layer = 0;
-  if (do_ray && Na <= c.N - 1) LAYU(SAMSIM_A_RAY, Na) = 0.0;
+  if (do_ray && Na <= c.N - 1 && (!whole_wave || x.ray_rows_all)) LAYU(SAMSIM_A_RAY, Na) = 0.0;
+  if (whole_wave) {
+    for (int w = 0; w <= (c.N - 1) >> 6; ++w) x.rflag[w] = 0ull;   // every lane writes the same zeros
+    __builtin_amdgcn_wave_barrier();
+  }
   // operands requested two layers ahead of the arithmetic, unconditionally and from a clamped row, as in sweep_up_fused.
   // The thickness rule (COLF_REGULAR) is checked against the array after samsim_set_state and after a regrid; in between -- the
   // steps of a melt season, which take this sweep because flush3 rewrites every layer -- nothing touches the thicknesses below
@@ -985,16 +1032,17 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x) {
       double S_bu, H;
       per_mass(S_abs, H_abs, m, S_bu, H);
       double T, phi = 0.0;
-      int rr = getT(s, H, S_bu, T_test, T, phi);
+      int rr = getT_chain(s, H, S_bu, T_test, T, phi);
       if (rr && !rc) { rc = rr; rc_layer = k; }
       T_test = T;
       // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
       LAYU(SAMSIM_A_T, k) = T;
-      LAYU(SAMSIM_A_PHI, k) = phi;
-      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r);
+      if (all_phi || k == 1 || k >= Na - 1) LAYU(SAMSIM_A_PHI, k) = phi;
+      s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r, whole_wave);
     }
   };
   if (check_wave) run(std::true_type{}); else run(std::false_type{});
+  if (whole_wave) { __builtin_amdgcn_wave_barrier(); c.ray_all = false; }   // the rows that hold a value are the flagged ones
   c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   c.flags = regular ? (c.flags | COLF_REGULAR) : (c.flags & ~COLF_REGULAR);
@@ -1039,6 +1087,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
   const bool transfer = (c.step + 1 != 1);
   double flm_k = 0.0;  // fl_m(k)
   double buoy_g = 0.0;
+  double fb_a2 = 0.0, fb_g2 = 0.0;   // SUM(psi_s*thick), SUM(psi_g*thick) over layers >= 2 for func_freeboard
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;  // layer k-1: snapshot T, S_br, UPDATED S_abs
   // rows are requested a chunk at a time (see RARE_CHUNK)
   constexpr int CH = RARE_CHUNK / 2;
@@ -1076,6 +1125,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
       psi_g = dmax((psi_g * thick - V_ex) / thick, 0.0);
     }
     if (psi_g > 0.0) buoy_g += psi_g * thick;
+    if (k >= 2) { fb_a2 += ex.psi_s * thick; fb_g2 += psi_g * thick; }
     LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
     LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
     LAY(SAMSIM_A_PSI_G, k) = psi_g;
@@ -1108,6 +1158,7 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     }
   }
   c.buoy_g = buoy_g;
+  SPEC(SP_FB_A2) = fb_a2; SPEC(SP_FB_G2) = fb_g2;
 }
 
 // ---------------------------------------------------------------- vital signs, mo_grotz.f90:192-223 (output only)
@@ -1489,7 +1540,8 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   const Salt &s = x.salt;
   const int Na = c.Na;
   const double dt = g.dt;
-  double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300, buoy_g = 0.0;
+  double heat_loss = 0.0, cum = 0.0, sum_before = 0.0, sum_after = 0.0, minS = 1.0e300;
+  double fb_a2 = 0.0, fb_g2 = 0.0;       // SUM(psi_s*thick), SUM(psi_g*thick) over layers >= 2 for func_freeboard (see there)
   int stop_layer = 0;
   bool store_psi = true;                 // layers 1 and 2 always; the others as decided after layer 2 (below)
   // conductive heat fluxes (sub_heat_fluxes, mo_heat_fluxes.f90:272-285): see C(j-1) below
@@ -1507,8 +1559,10 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // iteration of lead, a second finished layer -- 18 registers -- held for the sake of a test that is reached in a fifth of the
   // layers.  That test now forms S_br(j+1) from the request buffer on demand.)
   struct Ld { double T, S_abs, m, H_abs, ray; };
-  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, ray, H; };
+  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, rth, ray, H; };
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
+  // 1/thick of the two thicknesses of the grid rule, once per sweep (this sweep only runs on regular columns), and of layer 1
+  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAYU(SAMSIM_A_T, j);
@@ -1523,7 +1577,9 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   auto finish = [&](const Ld &l, int j) -> Raw {
     Raw r;
     r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.ray = l.ray;
-    r.thick = (j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
+    const bool mid = (j > g.n_top && j <= g.n_top + g.n_middle);
+    r.thick = (j >= 2) ? (mid ? th_mid : g.thick_0) : LAYU(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
+    r.rth = (j >= 2) ? (mid ? rth_mid : rth_0) : recip(r.thick);
     per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
@@ -1555,7 +1611,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
     double H_abs = raw.H_abs;
-    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, recip(thick));
+    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, raw.rth);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
@@ -1566,7 +1622,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       flm_next = -dmax((V_ex - psi_g * thick) * rho_l, 0.0);
       psi_g = dmax(quot(psi_g * thick - V_ex, thick), 0.0);
     }
-    if (psi_g > 0.0) buoy_g += psi_g * thick;
+    if (!FIRST) { fb_a2 += ex.psi_s * thick; fb_g2 += psi_g * thick; }
     // The up sweep only needs the layer's half resistance thick/(2k) (sub_fl_Q, mo_thermo_functions.f90:201-223); the three
     // volume fractions are stored when something reads them this step (see column_step), and always for layer 1
     if (store_psi || j == 1) {
@@ -1765,7 +1821,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   LAYU(SAMSIM_A_S_ABS, Na) = prev.S_abs;
   LAYU(SAMSIM_A_H_ABS, Na) = prev.H_abs;
   minS = dmin(minS, prev.S_abs);
-  c.buoy_g = buoy_g;
+  if (store_psi) { SPEC(SP_FB_A2) = fb_a2; SPEC(SP_FB_G2) = fb_g2; }   // (read by func_freeboard, which only runs where the rows were stored)
   CL(grav_salt) = CL(grav_salt) + sum_before;
   CL(grav_salt) = CL(grav_salt) - sum_after;
   if (stop_layer) STOPC(21234, stop_layer);
@@ -1912,6 +1968,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     for (int k = 1; k <= c.N - 1; ++k) x.out_lay[((size_t)SAMSIM_A_RAY * c.N + (k - 1)) * on + oc] = LAYU(SAMSIM_A_RAY, k);
   }
   for (int w = 0; w <= (c.N - 1) >> 6; ++w) x.rflag[w] = 0ull;   // every lane writes the same zeros
+  __builtin_amdgcn_wave_barrier();
   if (do_ray && Na <= c.N - 1 && x.ray_rows_all) LAYU(SAMSIM_A_RAY, Na) = 0.0;   // (read by `output` only)
   // The conductive update of layers >= 2 has been applied by the down sweep (sweep_down_fused / sweep_heat_down), which also
   // hands over fl_Q(2) and the energy sums: this sweep reads the finished enthalpy and runs the second getT chain -- and, for
@@ -1919,25 +1976,22 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // iterations ahead, unconditionally and from a clamped row where the layer does not exist: the hardware counts outstanding
   // memory operations in order, and the compiler can only wait for "all but the N youngest" when every path through the loop
   // body issues the same operations -- one conditional request and it falls back to draining them all.
+  // The thicknesses: a wave whose columns all follow the grid rule (COLF_REGULAR: every layer but the first is thick_0, except the
+  // N_middle elastic layers, which share thick(N_top+1)) walks the column in three stretches -- bottom block, elastic block, top
+  // block -- inside each of which thick and 1/thick are the same for every layer: the loop body neither loads nor selects them.  A
+  // wave with a hand-made column loads the array with the other operands and forms 1/thick per layer.
   struct UL { double th, H, m, S; };
-  const bool regular = (c.flags & COLF_REGULAR) != 0;
+  const bool regular_wave = __ballot((c.flags & COLF_REGULAR) == 0) == 0ull;
   const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-  // 1/thick of the two thicknesses of the grid rule, once per sweep (an irregular column forms it per layer)
   const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
-  auto load_ul = [&](int j) -> UL {
-    UL r;
-    r.th = (regular && j >= 2) ? thick_by_rule(j, g.n_top, g.n_middle, th_mid, g.thick_0) : LAYU(SAMSIM_A_THICK, j);
-    r.H = LAYU(SAMSIM_A_H_ABS, j); r.m = LAYU(SAMSIM_A_M, j); r.S = LAYU(SAMSIM_A_S_ABS, j);
-    return r;
-  };
-  UL cur = load_ul(Na), nxt = load_ul(Na >= 2 ? Na - 1 : 1), nn = nxt;   // layers k, k-1, k-2
+  UL cur, nxt, nn;
   bool alive = true;
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
   // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
   // thin-snow coupling (up to 200 getT pairs) nor its registers.
-  auto body = [&](const int k, auto top_tag) {
+  auto body = [&](const int k, const double th_k, const double rth_k, auto top_tag) {
     constexpr bool TOP = decltype(top_tag)::value;
-    const double th_k = cur.th, H_k = cur.H, m_k = cur.m, S_k = cur.S;
+    const double H_k = cur.H, m_k = cur.m, S_k = cur.S;
     double H_abs = H_k;
     const double m = m_k;
     if (TOP) {
@@ -1967,13 +2021,13 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     ST_MARK(ST_U_HEAD);
 #if SAMSIM_STAMPS == 2
     int evals = 1;
-    int rr = getT(s, H, S_bu, T_test, T, phi, &evals);
+    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi, &evals) : getT_chain(s, H, S_bu, T_test, T, phi, &evals);
     ST_COUNT(CT_UP_TRIPS, 1);
     ST_COUNT(CT_NEWTON_WAVE, (unsigned long long)wave_max(evals));
     { int tot = 0; unsigned long long mk = __ballot(1); while (mk) { const int ln = __ffsll((long long)mk) - 1; tot += __builtin_amdgcn_readlane(evals, ln); mk &= mk - 1; }
       ST_COUNT(CT_NEWTON_LANE, (unsigned long long)tot); }
 #else
-    int rr = getT(s, H, S_bu, T_test, T, phi);
+    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi) : getT_chain(s, H, S_bu, T_test, T, phi);
 #endif
     if (!TOP) { ISA_MARK("U_GETT_END"); }
     ST_MARK(ST_U_GETT);
@@ -1989,22 +2043,41 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
         c.flags |= COLF_DIRTY;
       }
-      const double rth_k = regular ? ((k > g.n_top && k <= g.n_top + g.n_middle) ? rth_mid : rth_0) : recip(th_k);   // (k >= 2 here)
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, rth_k, r, true);
     }
     ST_MARK(ST_U_TAIL);
   };
   const int kmax = wave_max(Na);
-  for (int k = kmax; k >= 2; --k) {
-    ISA_MARK("U_ITER_BEGIN");
-    ST_MARK(ST_UP);
-    if (k > Na) continue;
-    nn = load_ul(k >= 3 ? k - 2 : 1);
-    body(k, std::false_type{});
-    cur = nxt; nxt = nn;
-    ISA_MARK("U_ITER_END");
+  auto load3 = [&](int j) -> UL { UL u; u.th = 0.0; u.H = LAYU(SAMSIM_A_H_ABS, j); u.m = LAYU(SAMSIM_A_M, j); u.S = LAYU(SAMSIM_A_S_ABS, j); return u; };
+  auto load4 = [&](int j) -> UL { UL u = load3(j); u.th = LAYU(SAMSIM_A_THICK, j); return u; };
+  if (regular_wave) {
+    cur = load3(Na); nxt = load3(Na >= 2 ? Na - 1 : 1); nn = nxt;   // layers k, k-1, k-2
+    const int b0 = g.n_top, b1 = g.n_top + g.n_middle;
+    int k = kmax;
+    for (int stretch = 0; stretch < 3; ++stretch) {
+      const int klo = stretch == 0 ? b1 + 1 : (stretch == 1 ? b0 + 1 : 2);
+      const double th_s = stretch == 1 ? th_mid : g.thick_0, rth_s = stretch == 1 ? rth_mid : rth_0;
+      for (; k >= klo; --k) {
+        ISA_MARK("U_ITER_BEGIN");
+        ST_MARK(ST_UP);
+        if (k > Na) continue;
+        nn = load3(k >= 3 ? k - 2 : 1);
+        body(k, th_s, rth_s, std::false_type{});
+        cur = nxt; nxt = nn;
+        ISA_MARK("U_ITER_END");
+      }
+    }
+  } else {
+    cur = load4(Na); nxt = load4(Na >= 2 ? Na - 1 : 1); nn = nxt;
+    for (int k = kmax; k >= 2; --k) {
+      if (k > Na) continue;
+      nn = load4(k >= 3 ? k - 2 : 1);
+      body(k, cur.th, recip(cur.th), std::false_type{});
+      cur = nxt; nxt = nn;
+    }
   }
-  body(1, std::true_type{});
+  __builtin_amdgcn_wave_barrier();   // the row flags are complete: the next readers are the down sweeps of the next step
+  body(1, LAYU(SAMSIM_A_THICK, 1), 0.0, std::true_type{});
   if (!alive) return;
   // hand-over block for prologue_top_layer of the next step
   SPEC(SP_MINP) = r.minp; SPEC(SP_STP) = r.stp; SPEC(SP_ST) = r.st;
@@ -2726,6 +2799,7 @@ template <class K>
 __device__ RARE void refill_psi_rows(Col &c, const Ctx &x) {
   ST_COUNT(CT_REFILL, (unsigned long long)__popcll(__ballot(1)));
   THICK_RULE_INIT(tr);
+  double fb_a2 = LAY(SAMSIM_A_PSI_S, 2) * THICK_AT(tr, 2), fb_g2 = LAY(SAMSIM_A_PSI_G, 2) * THICK_AT(tr, 2);
   for (int k = 3; k <= c.Na; ++k) {
     const double m = LAY(SAMSIM_A_M, k), thick = THICK_AT(tr, k);
     double S_bu, H;
@@ -2735,7 +2809,9 @@ __device__ RARE void refill_psi_rows(Col &c, const Ctx &x) {
     LAY(SAMSIM_A_PSI_S, k) = e.psi_s;
     LAY(SAMSIM_A_PSI_L, k) = e.psi_l;
     LAY(SAMSIM_A_PSI_G, k) = e.psi_g;
+    fb_a2 += e.psi_s * thick; fb_g2 += e.psi_g * thick;
   }
+  SPEC(SP_FB_A2) = fb_a2; SPEC(SP_FB_G2) = fb_g2;
   c.psi_full = true;
 }
 
@@ -2779,7 +2855,9 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // first thermodynamic sweep, mo_grotz.f90:297-307 (+ Rayleigh numbers): only layer 1 is left to do unless the
   // column changed below layer 1 since the last up sweep
   c.ray_all = (c.flags & COLF_DIRTY) != 0;
-  if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); ST_COUNT(CT_L_DIRTY, (unsigned long long)__popcll(__ballot(1))); sweep_thermo_expulsion<K>(c, x); }
+  // (sparse Rayleigh rows need wave-uniform layer indices and every column of the wave in the sweep)
+  const bool whole_wave = __ballot(!c.ray_all) == 0ull;
+  if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); ST_COUNT(CT_L_DIRTY, (unsigned long long)__popcll(__ballot(1))); sweep_thermo_expulsion<K>(c, x, out_step, whole_wave); }
   else prologue_top_layer<K>(c, x);
   c.flags &= COLF_REGULAR;
   if (c.status) return;
@@ -3082,7 +3160,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   // row flags of the Rayleigh-number array (Ctx::rflag): at the start of a launch every row is valid (the last up sweep of a
   // launch stores all rows, as does samsim_set_state's full first sweep)
   __shared__ unsigned long long lds_rflag[SAMSIM_MAX_NLAYER / 64];
-  x.rflag = (lu64 *)lds_rflag;
+  x.rflag = (volatile lu64 *)lds_rflag;
   for (int w = 0; w < SAMSIM_MAX_NLAYER / 64; ++w) x.rflag[w] = ~0ull;
   // the LDS-resident scalars (each lane reads and writes only its own words: no barrier needed)
   __shared__ double lds_scal[LD_NSLOT * SAMSIM_BLOCK];

@@ -4,8 +4,9 @@
 // (not double-double) logarithm is enough: an absolute error e in log(x) shows up as 0.1*e relative in the result.  log(x) =
 // E*ln2 + 2*atanh(s), s = (m-1)/(m+1), m in [sqrt(1/2), sqrt(2)); exp by n*ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial.
 // Within ~3 ulp of the correctly rounded power (tests/test_host_logic.py checks it on the CPU against math.pow with
-// this header compiled for the host; tools/div_probe checks it on the GPU), about 60 vector instructions instead of the 139 of
-// exp(3.1*log(x)) and the 214 of pow().  Included by samsim_kernels.hip and by tools/pow_host.c.
+// this header compiled for the host), about 60 vector instructions instead of the 139 of exp(3.1*log(x)) and the 214 of pow().
+// On the GPU the power goes through a hardware-seeded tenth root (sp_pow_3p1 below; tools/div_probe measures both forms against
+// pow() there).  Included by samsim_kernels.hip, tools/div_probe.hip and tools/pow_host.c.
 #ifndef SAMSIM_POW_H
 #define SAMSIM_POW_H
 
@@ -95,10 +96,29 @@ SP_FN double sp_exp(double y) {
   return SP_LDEXP(p, (int)n);
 }
 
-// x**3.1, x >= 0 (0 -> 0; a cube that underflows gives 0 like the product 1e-17 * x**3.1 it feeds)
-SP_FN double sp_pow_3p1(double x) {
+// x**3.1, x >= 0 (0 -> 0; a cube that underflows gives 0 like the product 1e-17 * x**3.1 it feeds): the plain form
+SP_FN double sp_pow_3p1_plain(double x) {
   const double x3 = x * x * x;
   if (!(x3 > 0.0)) return x3;
   return x3 * sp_exp(0.1 * sp_log(x));
 }
+
+// The same through a tenth root: y = x**0.1 seeded by the hardware's single-precision log2 / exp2 (v_log_f32, v_exp_f32: relative
+// error of the seed e0 ~ 2e-7 for 2^-100 <= x <= 2^100) and ONE Halley step on y**10 = x,
+//     y <- y * (9 y**10 + 11 x) / (11 y**10 + 9 x),      error 8.25 * e0**3 ~ 1e-19,
+// so the root is as good as its six roundings (2-3 ulp), and x**3.1 = x*x*x*y within ~4 ulp of the correctly rounded power like the
+// plain form -- in 26 vector instructions instead of 63.  Outside that range of x (a liquid fraction below 1e-33, zero, NaN) the
+// plain form is taken, per lane: a column's bits never depend on its wave-mates.
+#if defined(__HIPCC__)
+SP_FN double sp_pow_3p1(double x) {
+  if (!(x >= 0x1p-100 && x <= 0x1p100)) return sp_pow_3p1_plain(x);
+  const double x3 = x * x * x;
+  const double y = (double)__builtin_amdgcn_exp2f(0.1f * __builtin_amdgcn_logf((float)x));
+  const double y2 = y * y, y4 = y2 * y2, y8 = y4 * y4, t = y8 * y2;
+  const double num = SP_FMA(9.0, t, 11.0 * x), den = SP_FMA(11.0, t, 9.0 * x);
+  return x3 * (y * SP_QUOT(num, den));
+}
+#else
+SP_FN double sp_pow_3p1(double x) { return sp_pow_3p1_plain(x); }
+#endif
 #endif

@@ -16,3 +16,27 @@ def pytest_configure(config):
 def oracle_lib():
     from tests.oracle_lib import load_oracle
     return load_oracle()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _background_free_runs(request):
+    """the two long single-wave free runs of the GPU suite start with the session's first GPU test and run beside the others
+    (tests/background_runs.py); nothing happens in a CPU session"""
+    gpu_session = any(item.get_closest_marker("gpu") is not None for item in request.session.items)
+    started = False
+    if gpu_session:
+        try:
+            import ctypes
+            import samsim_amd
+            lib = samsim_amd.load()
+            lib.samsim_device_count.restype = ctypes.c_int
+            if lib.samsim_device_count() > 0 and len([i for i in request.session.items if i.get_closest_marker("gpu")]) > 10:
+                from tests import background_runs
+                background_runs.start_all()
+                started = True
+        except Exception:      # noqa: BLE001  (a missing library is the GPU tests' own failure to report)
+            started = False
+    yield
+    if started:
+        from tests import background_runs
+        background_runs.stop_all()

@@ -250,17 +250,29 @@ def test_launch_without_forcing_tables_is_refused():
         assert e.value.code == -1, bf
 
 
-def test_division_sequences_return_ieee_quotients():
-    """samsim_div.h forms 1/x and a/b of the fused sweeps by the compiler's Newton sequence without operand scaling and
-    special-case fix-up; tools/div_probe (built by __graft_entry__.build()) compares them with 1.0/x and a/b on 2^26
-    operand pairs over 1e-12..1e12: no bit may differ"""
+def test_division_and_power_sequences_stay_within_an_ulp_or_four():
+    """samsim_div.h forms 1/x and a/b of the sweeps by the arithmetic core of the compiler's division sequence (no operand
+    scaling, no special-case fix-up, one Newton step less); samsim_pow.h forms x**3.1 through a hardware-seeded tenth root.
+    tools/div_probe (built by __graft_entry__.build()) measures them on the GPU against 1.0/x, a/b and pow(x, 3.1) on 2^26
+    operands each: the quotients within ONE ulp (observed: none differs), the two forms of the power within 1.5e-15 of each other"""
+    import re
     import subprocess
     exe = os.path.join(ROOT, "tools", "div_probe")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "samsim_amd", "csrc"), "div_probe"])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "recip != 1.0/x: 0 " in out.stdout and out.stdout.rstrip().endswith("quot != a/b: 0"), out.stdout
+    print(out.stdout)
+    m = re.search(r"recip != 1.0/x: (\d+) \(max (\d+) ulp\)  quot != a/b: (\d+) \(max (\d+) ulp\)", out.stdout)
+    assert m, out.stdout
+    assert int(m.group(2)) <= 1 and int(m.group(4)) <= 1, out.stdout
+    m = re.search(r"max rel err ([0-9.e+-]+) \(plain form ([0-9.e+-]+)\); tenth-root form vs plain form: ([0-9.e+-]+); (\d+) arguments "
+                  r"below 2\^-100 \(plain form\): ([0-9.e+-]+)", out.stdout)
+    assert m, out.stdout
+    # the plain form is pinned on the CPU against the exact power (tests/test_host_logic.py: 7e-16); the tenth-root form against it here
+    assert float(m.group(3)) <= 1.5e-15, out.stdout
+    assert float(m.group(1)) <= 2e-14 and float(m.group(2)) <= 2e-14, out.stdout     # (the device's own pow() is good to ~7e-15)
+    assert int(m.group(4)) > 1000 and float(m.group(5)) <= 1e-13, out.stdout         # liquid fractions below 1e-33: |log x| up to 200
 
 
 def test_unsupported_flags_are_rejected():
@@ -455,13 +467,17 @@ def test_per_column_ocean_grid_of_columns():
     g, o = pair(cfg, ncol, st, forcing=sheba_forcing())
     for s in (g, o):
         s.set_ocean(dq, sb)
-    # Free run through open water and the first ice (day 64), then ONE-DAY windows restarted from the checker's state every second
-    # day up to day 100.  Why windows: two events of the freeze-up amplify round-off -- the first ice layer (day 64-65) and the
-    # first, thinner-than-thick_min snow on three to five layers of ice (day 66-67, the thin-snow coupling's fixed-size enthalpy
-    # steps).  profiles/r3_freeze_up_sensitivity*.json shows it without any GPU: the checker against its own -ffp-contract=fast
-    # build, same 64 columns, parts by up to 3e-4 in 10 columns exactly there in a free run (which is what round 2's free run to
-    # day 75 had met: 4e-5), and stays below 3e-13 on every one-day window from day 68 on (profiles/r3_freeze_up_windows_1day.json).
-    # So: the two windows that hold the events at the parity bar, every later one at 1e-9 like the main path's reference windows.
+    # Free run through open water to the first ice (day 64), then windows restarted from the checker's state.  Why windows: two
+    # events of the freeze-up amplify round-off -- the first ice layer (day 64-65) and the first snow growing through thick_min on
+    # three to five layers of ice (day 66-67: the thin-snow coupling's fixed-size enthalpy steps, then the switch of the surface
+    # balance at thick_min).  profiles/r3_freeze_up_*.json shows it without any GPU: the checker against its own
+    # -ffp-contract=fast build, same 64 columns, parts by up to 3e-4 in 10 columns exactly there in a free run (which is what round
+    # 2's free run to day 75 had met: 4e-5); a window of only 1 500 steps started at day 67, when the snow of several columns is
+    # within a few per cent of thick_min, already shows 2e-3 (profiles/r3_freeze_up_windows_days64_68.json; the HIP path: 3e-4),
+    # the 1 500-step windows of days 64, 65, 66 and 68 stay below 1e-13, and so does every ONE-DAY window from day 68 on
+    # (profiles/r3_freeze_up_windows_1day.json: 3e-13).  So: 1 500-step windows at days 64, 65, 66 at the parity bar, the one at
+    # day 67 held to the size of that event, and from day 68 one-day windows every second day at 1e-9, like the main path's
+    # windows from the reference's records.
     n = 8641 * 64
     g.step(n)
     o.step(n)
@@ -469,21 +485,25 @@ def test_per_column_ocean_grid_of_columns():
     assert np.array_equal(sg.sc("S_bu_bottom"), sb)
     spread = set()
     worst_late = 0.0
-    for day in range(64, 100, 2):
+    day = 64
+    while day < 100:
         k = o.get_clock()
         assert k.step == 8641 * day
+        window = 1500 if day < 68 else 8641
         g.set_state(o.get_state())
         g.set_clock(time=k.time, step=k.step, n_time_out=k.n_time_out, time_counter=k.time_counter, n_outputs=k.n_outputs)
-        g.step(8641)
-        o.step(8641)
-        sg, so = check(g, o, f"ocean grid, day {day} -> {day + 1}")
+        g.step(window)
+        o.step(window)
+        sg, so = check(g, o, f"ocean grid, {window} steps from day {day}", rtol=5e-3 if day == 67 else 1e-6)
         spread.update(int(v) for v in so.n_active)
         if day >= 68:
             kk = np.arange(sg.nlayer)[:, None] < so.n_active[None, :]
             for name in ("H_abs", "S_abs", "m", "thick", "T"):
                 floor = 1e-3 if name == "H_abs" else 1e-9
                 worst_late = max(worst_late, rel_err(sg.arr(name)[kk], so.arr(name)[kk], floor))
-        o.step(8641)
+        step_to = 1 if day < 68 else 2
+        o.step(8641 * step_to - window)
+        day += step_to
     print(f"ocean grid: worst one-day window from day 68 on {worst_late:.2e}")
     assert worst_late <= 1e-9
     assert len(spread) > 8                                                  # the oceans spread the ensemble

@@ -80,13 +80,10 @@ def test_sheba_free_run_from_open_water_against_the_reference_records():
     flang-built reference's own record of that day: the scalars of all 300 days (tc4_ref_fullprec.npz all_s_*), the layer arrays on
     the days the fixture holds them (day_index).  The reference's -O2 and FMA builds stay within 2e-12 of each other over this
     span; the first melt season (day 347 on) is where free runs part, and is covered by the windows above."""
+    from tests import background_runs
     ref = golden("tc4_ref_fullprec.npz")
-    cfg, st = tcs.testcase4(1)
-    g = samsim_amd.hip_solver(cfg, 1)
-    g.set_forcing(*sheba_forcing())
-    g.set_state(st)
-    g.set_clock()
-    g.set_output_window(0, 1)
+    run = background_runs.get("sheba_free_run")       # started with the session's first GPU test: it has been running beside the others
+    outputs = run.result()
     layer_days = {int(d): j for j, d in enumerate(ref["day_index"])}      # output number (1-based) -> row of the a_* block
     last, worst, worst_at = 301, 0.0, None
     scalars = (("thickness", 1e-7), ("bulk_salin", 1e-7), ("freeboard", 1e-7), ("energy_stored", 1e-3), ("freshwater", 1e-7),
@@ -94,8 +91,8 @@ def test_sheba_free_run_from_open_water_against_the_reference_records():
                ("T2m", 1e-2), ("fl_q_bottom", 1e-7), ("albedo", 1e-7), ("fl_sw", 1e-7), ("fl_lw", 1e-7), ("grav_drain", 1e-12),
                ("grav_salt", 1e-9), ("grav_temp", 1e-6), ("melt_out1", 1e-9), ("melt_out2", 1e-9), ("melt_out3", 1e-9))
     seen_layers = 0
-    for i in range(last):                                                  # output i is the reference's output day i (0-based)
-        out = g.run_to_output()
+    assert len(outputs) == last
+    for i, out in enumerate(outputs):                                      # output i is the reference's output day i (0-based)
         assert out.step == ref["all_step"][i], (i, out.step, ref["all_step"][i])
         assert out.n_active[0] == ref["all_N_active"][i], f"output {i}: N_active {out.n_active[0]} vs {ref['all_N_active'][i]}"
         for n, floor in scalars:
@@ -113,7 +110,7 @@ def test_sheba_free_run_from_open_water_against_the_reference_records():
                 if e > worst:
                     worst, worst_at = e, (i, n)
                 assert e <= RTOL, f"free run, output day {i}: layers of {n} rel err {e:.2e} vs the reference record"
-    assert not g.get_status()[0].any()
+    assert not run.status.any()
     assert seen_layers >= 15 and out.n_active[0] == 100                    # layer records through freeze-up and growth were compared
     print(f"free run to output day {last - 1}: worst relative deviation from the reference's records {worst:.2e} at {worst_at}")
     assert worst <= 1e-8   # (the bar is 1e-6; a free run that stays this close did not meet an amplifying event)

@@ -232,6 +232,52 @@ def test_grid_of_columns_on_all_nine_forcing_sites():
     assert len({round(float(T2m[site == k].mean()), 3) for k in range(nsite)}) == nsite      # the sites really differ
 
 
+def test_the_five_later_era_sites_free_run_against_the_reference_records():
+    """SURVEY.md 8 f.4 against the reference itself: testcase 4 on the tables of 75N180E, 80N00E, 75N00W, 85N180E and 80N90E
+    (input/ERA-interim/<site>-p2/), one unperturbed column per site in ONE handle (samsim_set_forcing_sites: the KShebaSites
+    instantiation), free from open water; every output day of the 150 the reference was run for against its own record of that day
+    (tests/golden/tc4_sites_ref.npz: scalars of all days, layer arrays on the days the fixture holds them).
+    80N90E meets a freeze-up event that amplifies round-off on output day 61 (ice of 8-9 layers melting back to 6): the checker
+    and its own -ffp-contract=fast build part by 4e-4 there, the other four sites stay below 2e-12 for all 150 days
+    (profiles/r3_site_sensitivity.json, CPU only).  So 80N90E is held to the parity bar up to day 60 and to the size of that event
+    afterwards; the other sites to the parity bar throughout."""
+    from tests import background_runs
+    more = background_runs.SITES
+    run = background_runs.get("sites_free_run")       # started with the session's first GPU test: it has been running beside the others
+    outputs = run.result()
+    assert len(outputs) == 150
+    z = golden("tc4_sites_ref.npz")
+    rows = {s: {int(x): j for j, x in enumerate(z[f"{s}_index"])} for s in more}
+    scalars = (("thickness", 1e-7), ("bulk_salin", 1e-7), ("freeboard", 1e-7), ("m_snow", 1e-5), ("thick_snow", 1e-7), ("T_snow", 1e-2),
+               ("T_top", 1e-2), ("T2m", 1e-2), ("energy_stored", 1e-3), ("total_resist", 1e-7), ("grav_salt", 1e-9))
+    worst = {s: 0.0 for s in more}
+    layer_days = 0
+    for i, out in enumerate(outputs):
+        for c, s in enumerate(more):
+            event = s == "80N90E" and i >= 60
+            tol = 5e-3 if event else RTOL
+            assert out.step == z[f"{s}_all_step"][i]
+            if not event:
+                assert out.n_active[c] == z[f"{s}_all_N_active"][i], f"{s} output {i}: N_active {out.n_active[c]} vs {z[f'{s}_all_N_active'][i]}"
+            for n, floor in scalars:
+                e = rel_err(out.sc(n)[c], z[f"{s}_all_s_{n}"][i], floor)
+                if not event:
+                    worst[s] = max(worst[s], e)
+                assert e <= tol, f"{s} output day {i}: {n} = {out.sc(n)[c]!r} vs the reference's {z[f'{s}_all_s_{n}'][i]!r} ({e:.2e})"
+            if i in rows[s] and not event:
+                j, na = rows[s][i], int(out.n_active[c])
+                layer_days += 1
+                for n in ["T", "psi_s", "psi_l", "S_bu", "thick", "H_abs", "S_abs", "m"]:
+                    floor = 1e-3 if n == "H_abs" else 1e-9
+                    e = rel_err(out.arr(n)[:na, c], z[f"{s}_a_{n}"][j, :na], floor)
+                    worst[s] = max(worst[s], e)
+                    assert e <= RTOL, f"{s} output day {i}: layers of {n} rel err {e:.2e} vs the reference record"
+    assert not run.status.any()
+    assert layer_days >= 12 and out.n_active.max() >= 90
+    print("five sites, free run of 150 output days: worst relative deviation from the reference's records", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) <= 1e-8
+
+
 VARIANTS = {"prescribe": dict(flush_flag=4, grav_flag=1, flood_flag=1, prescribe_flag=2), "flush6": dict(flush_flag=6)}
 
 

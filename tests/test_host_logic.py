@@ -183,3 +183,45 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", inc, str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout
+
+
+def test_checkpoint_layout_without_the_status_block_is_refused(tmp_path):
+    """the chunk layout changed when checkpoints began to carry the STOP codes: files of the older layout carry another magic
+    ("SAMCHK01") and are refused, not mis-read"""
+    import struct
+    from samsim_amd import checkpoint
+    p = tmp_path / "old.chk"
+    p.write_bytes(struct.pack("<6q d 4q 5q", int.from_bytes(b"SAMCHK01", "little"), 4, 90, 15, 38, 1, 0.0, 0, 0, 1, 0, 0, 0, 0, 0, 0))
+    with pytest.raises(ValueError, match="SAMCHK01"):
+        checkpoint.read_header(str(p))
+    p.write_bytes(struct.pack("<6q d 4q 5q", checkpoint.MAGIC, 4, 90, 15, 38, 1, 0.0, 7, 0, 1, 0, 0, 1, 0, 0, 0))
+    assert checkpoint.read_header(str(p))["step"] == 7
+
+
+def test_plain_form_of_the_permeability_power_against_the_exact_power(tmp_path):
+    """samsim_pow.h compiled for the host: x**3.1 as x*x*x * exp(0.1 * log x) (the form the kernel keeps for liquid fractions below
+    1e-33, and the reference of its tenth-root form on the GPU, tools/div_probe) against powl(x, 3 + 0.1) over the range of the
+    permeability law, 1e-9 .. 3000: within 1e-15 relative"""
+    import os
+    import subprocess
+    src = tmp_path / "powtest.c"
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "samsim_amd", "csrc", "samsim_pow.h")
+    src.write_text('''#include <stdio.h>
+#include <math.h>
+#include "%s"
+int main(void) {
+  double mx = 0.0;
+  const long double e = (long double)3.0 + (long double)0.1;   /* the exponent the form evaluates: 3 + the double 0.1 */
+  for (int i = 0; i < 4000000; i++) {
+    const double u = (i + 0.5) / 4000000.0, x = exp(log(1e-9) + u * (log(3000.0) - log(1e-9)));
+    const double r = (double)powl((long double)x, e), err = fabs(sp_pow_3p1_plain(x) - r) / r;
+    if (err > mx) mx = err;
+  }
+  printf("%%.3e\\n", mx);
+  return 0;
+}
+''' % hdr)
+    exe = tmp_path / "powtest"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"])
+    worst = float(subprocess.check_output([str(exe)]).decode())
+    assert worst <= 1e-15, worst

@@ -1,38 +1,46 @@
-// layout_probe.hip -- does the memory layout of the layer block matter for this path's access pattern?
-// One lane walks its column twice per "step" (down: 7 loads + 4 stores per layer, up: 6 loads + 4 stores per layer) with a
-// dependent FP64 chain per layer and 4 waves/SIMD, like samsim_step_kernel.  Layout A = [array][layer][column] (8 MB between
-// two rows at 1 M columns), layout B = [column block of 64][layer][array][64 lanes] (a wave's whole column block is one
-// contiguous 0.6 MB piece).
-//   hipcc --offload-arch=gfx950 -O3 tools/layout_probe.hip -o tools/layout_probe && tools/layout_probe
+// layout_probe.hip -- what does the memory system give this path's access pattern, and does the position of the hot arrays matter?
+// One lane walks its column twice per "step" exactly as the fused sweeps of samsim_step_kernel do: down (top -> bottom) loads T, S_abs,
+// m, H_abs of a layer and stores m, S_abs, H_abs; up (bottom -> top) loads H_abs, m, S_abs and stores T: 7 loads + 4 stores = 88 bytes
+// per layer-cell, with a dependent FP64 chain per layer (WORK fused multiply-adds down, 2 WORK up), 4 waves/SIMD, rows requested where
+// they are used.  Layouts of the layer block (NA = 16 arrays of NL layers):
+//   0  [block64][layer][array][lane], hot arrays H_abs, S_abs, m at 0..2 and T at 4 (round 2 / the product's order: thick sits between)
+//   1  the same with T at 3: the four hot arrays of a layer row are one contiguous 2 KB piece
+//   2  [block64][array][layer][lane]: consecutive layers of one array are contiguous (512 B apart), arrays NL * 512 B apart
+//   3  [array][layer][column] (round 1: 8 MB between two rows at 1 M columns)
+//   hipcc --offload-arch=gfx950 -O3 tools/layout_probe.hip -o tools/layout_probe && tools/layout_probe [WORK]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
-constexpr int NA = 12, NL = 80, WORK = 24;
+constexpr int NA = 16, NL = 80;
 
-template <bool BLOCKED>
+template <int LAYOUT>
 __device__ __forceinline__ size_t idx(size_t ncol, size_t col, int a, int k) {
-  if (BLOCKED) return ((col >> 6) * (size_t)(NL * NA) + (size_t)(k * NA + a)) * 64 + (col & 63);
+  if (LAYOUT == 0 || LAYOUT == 1) return ((col >> 6) * (size_t)(NL * NA) + (size_t)(k * NA + a)) * 64 + (col & 63);
+  if (LAYOUT == 2) return ((col >> 6) * (size_t)(NL * NA) + (size_t)(a * NL + k)) * 64 + (col & 63);
   return ((size_t)a * NL + k) * ncol + col;
 }
 
-template <bool BLOCKED>
-__global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t ncol, int steps) {
+template <int LAYOUT>
+__global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t ncol, int steps, int work) {
   extern __shared__ double pad[];          // sized so that 16 blocks fit a CU: 4 waves / SIMD
   const size_t col = (size_t)blockIdx.x * 64 + threadIdx.x;
+  constexpr int H = 0, S = 1, M = 2, T = (LAYOUT == 0) ? 4 : 3;
   double carry = 0.0;
   for (int s = 0; s < steps; ++s) {
     for (int k = 0; k < NL; ++k) {                       // down sweep
-      double v = carry;
-      for (int a = 0; a < 7; ++a) v += lay[idx<BLOCKED>(ncol, col, a, k)];
-      for (int i = 0; i < WORK; ++i) v = v * 1.0000001 + 1e-9;
-      for (int a = 7; a < 11; ++a) lay[idx<BLOCKED>(ncol, col, a, k)] = v + a;
+      double v = carry + lay[idx<LAYOUT>(ncol, col, T, k)] + lay[idx<LAYOUT>(ncol, col, S, k)] + lay[idx<LAYOUT>(ncol, col, M, k)] +
+                 lay[idx<LAYOUT>(ncol, col, H, k)];
+      for (int i = 0; i < work; ++i) v = v * 1.0000001 + 1e-9;
+      lay[idx<LAYOUT>(ncol, col, M, k)] = v + 1.0;
+      lay[idx<LAYOUT>(ncol, col, S, k)] = v + 2.0;
+      lay[idx<LAYOUT>(ncol, col, H, k)] = v + 3.0;
       carry = v * 1e-3;
     }
     for (int k = NL - 1; k >= 0; --k) {                  // up sweep
-      double v = carry;
-      for (int a = 5; a < 11; ++a) v += lay[idx<BLOCKED>(ncol, col, a, k)];
-      for (int i = 0; i < 2 * WORK; ++i) v = v * 1.0000001 + 1e-9;
-      for (int a = 0; a < 4; ++a) lay[idx<BLOCKED>(ncol, col, a, k)] = v * 1e-6 + a;
+      double v = carry + lay[idx<LAYOUT>(ncol, col, H, k)] + lay[idx<LAYOUT>(ncol, col, M, k)] + lay[idx<LAYOUT>(ncol, col, S, k)];
+      for (int i = 0; i < 2 * work; ++i) v = v * 1.0000001 + 1e-9;
+      lay[idx<LAYOUT>(ncol, col, T, k)] = v * 1e-6;
       carry = v * 1e-3;
     }
   }
@@ -41,25 +49,35 @@ __global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t n
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-int main() {
+template <int LAYOUT>
+int run(double *lay, size_t ncol, int steps, int work, const char *name) {
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  const double bytes = (double)ncol * NL * (7 + 4) * 8.0 * steps;
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    float ms;
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(walk<LAYOUT>, dim3(ncol / 64), dim3(64), 10000, 0, lay, ncol, steps, work);
+    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("work %3d  %-58s: %7.1f ms  %5.0f GB/s of the 88 B per layer-cell\n", work, name, best, bytes / 1e6 / best);
+  return 0;
+}
+
+int main(int argc, char **argv) {
   const size_t ncol = 1 << 20;
   double *lay;
   CHK(hipMalloc(&lay, ncol * NA * NL * sizeof(double)));
   CHK(hipMemset(lay, 0, ncol * NA * NL * sizeof(double)));
-  hipEvent_t e0, e1;
-  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   const int steps = 10;
-  const double bytes = (double)ncol * NL * (7 + 4 + 6 + 4) * 8.0 * steps;
-  for (int rep = 0; rep < 3; ++rep) {
-    float ms;
-    CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(walk<false>, dim3(ncol / 64), dim3(64), 10000, 0, lay, ncol, steps);
-    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
-    printf("layout A [array][layer][column]       : %.1f ms  %.0f GB/s logical\n", ms, bytes / 1e6 / ms);
-    CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(walk<true>, dim3(ncol / 64), dim3(64), 10000, 0, lay, ncol, steps);
-    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
-    printf("layout B [block64][layer][array][lane]: %.1f ms  %.0f GB/s logical\n", ms, bytes / 1e6 / ms);
+  for (int a = 1; a < (argc > 1 ? argc : 2); ++a) {
+    const int work = argc > 1 ? atoi(argv[a]) : 24;
+    if (run<0>(lay, ncol, steps, work, "[block][layer][array][lane], T behind thick (the product)")) return 1;
+    if (run<1>(lay, ncol, steps, work, "[block][layer][array][lane], H_abs S_abs m T contiguous")) return 1;
+    if (run<2>(lay, ncol, steps, work, "[block][array][layer][lane]")) return 1;
+    if (run<3>(lay, ncol, steps, work, "[array][layer][column]")) return 1;
   }
   return 0;
 }
