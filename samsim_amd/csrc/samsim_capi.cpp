@@ -59,6 +59,8 @@ struct samsim_handle {
   double *spec = nullptr;      // hand-over block of the up sweep, [DEV_NSPEC][ncol]
   int32_t *flags = nullptr;    // COLF_* per column
   void *d_stat = nullptr;      // block partials of samsim_get_ensemble_stats
+  double *stage = nullptr;     // staging buffer of samsim_set_state / samsim_get_state (boundary layout), grown on demand and kept:
+  size_t stage_n = 0;          // no hipMalloc / hipFree -- both wait for the whole device -- per call
   // passive tracers (bgc_flag 2)
   double *bgc = nullptr, *bgc_bot = nullptr, *bfl = nullptr, *out_bgc = nullptr, *out_bgc_bot = nullptr;
   int32_t n_bgc = 0;
@@ -85,6 +87,16 @@ struct samsim_handle {
 };
 
 namespace {
+
+// the handle's staging buffer with room for n doubles
+hipError_t stage_for(samsim_handle *h, size_t n) {
+  if (n <= h->stage_n) return hipSuccess;
+  (void)hipFree(h->stage);
+  h->stage = nullptr; h->stage_n = 0;
+  hipError_t e = hipMalloc((void **)&h->stage, n * sizeof(double));
+  if (e == hipSuccess) h->stage_n = n;
+  return e;
+}
 
 int validate(const samsim_config &c) {
   if (c.struct_size != (int32_t)sizeof(samsim_config)) return SAMSIM_ERR_ABI;
@@ -396,7 +408,7 @@ void samsim_destroy(samsim_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->lay); (void)hipFree(h->scal); (void)hipFree(h->n_active); (void)hipFree(h->status);
   (void)hipFree(h->err_layer); (void)hipFree(h->err_step); (void)hipFree(h->work);
-  (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat);
+  (void)hipFree(h->spec); (void)hipFree(h->flags); (void)hipFree(h->d_stat); (void)hipFree(h->stage);
   (void)hipFree(h->bgc); (void)hipFree(h->bgc_bot); (void)hipFree(h->bfl); (void)hipFree(h->out_bgc); (void)hipFree(h->out_bgc_bot);
   (void)hipFree(h->f_sw); (void)hipFree(h->f_lw); (void)hipFree(h->f_T2m); (void)hipFree(h->f_precip); (void)hipFree(h->site);
   (void)hipFree(h->ocean_dflq); (void)hipFree(h->ocean_sbu);
@@ -496,17 +508,12 @@ int samsim_set_state(samsim_handle *h, const samsim_state_soa *s, int64_t col0) 
   HIPCHK(hipStreamSynchronize(h->stream));
   {
     const size_t n = (size_t)s->narr * N * w;
-    double *stage = nullptr;
-    HIPCHK(dalloc(&stage, n));
-    hipError_t e = hipMemcpy(stage, s->lay, n * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(lay_window<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, stage, (int)s->narr, (int)N, nc,
-                         (size_t)col0, w);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(stage);
-    HIPCHK(e);
+    HIPCHK(stage_for(h, n));
+    HIPCHK(hipMemcpyAsync(h->stage, s->lay, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(lay_window<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, h->stage, (int)s->narr, (int)N, nc,
+                       (size_t)col0, w);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
   }
   // the perturbation slots (>= SAMSIM_S_DT2M) belong to the forcing: set_state leaves them alone
   HIPCHK(hipMemcpy2D(h->scal + col0, nc * sizeof(double), s->scal, w * sizeof(double), w * sizeof(double), (size_t)SAMSIM_S_DT2M,
@@ -535,15 +542,12 @@ int samsim_get_state(samsim_handle *h, samsim_state_soa *s, int64_t col0) {
   HIPCHK(hipStreamSynchronize(h->stream));
   {
     const size_t n = (size_t)s->narr * N * w;
-    double *stage = nullptr;
-    HIPCHK(dalloc(&stage, n));
-    hipLaunchKernelGGL(lay_window<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, stage, (int)s->narr, (int)N, nc,
+    HIPCHK(stage_for(h, n));
+    hipLaunchKernelGGL(lay_window<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lay, h->stage, (int)s->narr, (int)N, nc,
                        (size_t)col0, w);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(s->lay, stage, n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(stage);
-    HIPCHK(e);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(s->lay, h->stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
   }
   HIPCHK(hipMemcpy2D(s->scal, w * sizeof(double), h->scal + col0, nc * sizeof(double), w * sizeof(double), (size_t)SAMSIM_NSCAL,
                      hipMemcpyDeviceToHost));

@@ -56,7 +56,7 @@ enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_
        CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
        CT_DRAIN_LANE, CT_DIRTY, CT_L_COUPLING, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B,
        CT_L_FLOODP = 25, CT_L_IRREG, CT_L_DIRTY, CT_L_UNFUSED, CT_L_FLUSH3, CT_L_REGRID, CT_L_FREEBOARD,
-       CT_REFILL = 32, ST_NSLOT = 48 };
+       CT_REFILL = 32, CT_ROWS, CT_ROWS_STILL, ST_NSLOT = 48 };
 struct Stamps {
   unsigned long long *acc;   // [48] in LDS, one block = one wave
   unsigned long long t0;
@@ -201,8 +201,7 @@ struct Col {
   int Na;       // N_active
   int flags;          // COLF_*
   gdouble *spec;       // UNIFORM base of the [DEV_NSPEC][ncol] hand-over block
-  int status, err_layer;
-  long long err_step;
+  int status;      // 0 or the reference's STOP code; where and when it stopped goes straight to the err_layer / err_step arrays
   long long step;  // completed steps; i = step + 1
   // per-column scalars (enum samsim_scalar)
   double fl_q_bottom;
@@ -254,6 +253,10 @@ struct Col {
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
+// experiment: the fused up sweep requests its operands 3 layers ahead instead of 2
+#ifndef SAMSIM_UAHEAD
+#define SAMSIM_UAHEAD 2
+#endif
 static_assert(SAMSIM_BLOCK == 64, "the blocked layer layout, launch() and DEV_LAY_INDEX are written for one 64-lane wave per column block");
 // Address of element (a, k): one 32-bit offset register per row serves all arrays of the row (a 64-bit per-lane address for every
 // array costs two registers each and 64-bit vector arithmetic per access).
@@ -269,8 +272,8 @@ static_assert(SAMSIM_BLOCK == 64, "the blocked layer layout, launch() and DEV_LA
   do {                                \
     if (!c.status) {                  \
       c.status = (code);              \
-      c.err_step = c.step + 1;        \
-      c.err_layer = (layer);          \
+      x.err_step[c.col] = c.step + 1; \
+      x.err_layer[c.col] = (layer);   \
     }                                 \
     return;                           \
   } while (0)
@@ -383,14 +386,26 @@ __device__ __forceinline__ void newton_terms(const Salt &s, double H, double S_b
 // |N| > sb**2 (the reference's |f| > 1), ok = the liquidus salinity at T_0 is above 1e-4, i.e. the reference's clamps of S_br
 // (1e-9 / 1e-10) are inactive and this form is the step.  A0 = -latent_heat - H and LS = latent_heat * S_bu are the caller's
 // (the same for every evaluation of a layer).  Straight-line: no branch, 23 vector instructions.
-__device__ __forceinline__ void newton_eval(const Salt &s, double A0, double LS, double T_0, double &T_new, bool &more, bool &ok) {
-  const double sbf = T_0 * __builtin_fma(T_0, __builtin_fma(T_0, s.c4, s.c3), s.c2);
+// Three of its fused multiply-adds have a constant multiplier AND a constant addend (c3, c_s twice, 2*d3); the instruction takes one
+// operand from a scalar register, so the compiler copies the other into a vector register pair first -- two v_mov_b32 per constant
+// and evaluation, re-done inside getT's loop (no hoisting: Makefile).  NewtonConsts holds those three as vector values the caller
+// forms once per layer.
+struct NewtonConsts { double c3, cs, d3x2; };
+__device__ __forceinline__ NewtonConsts newton_consts(const Salt &s) {
+  NewtonConsts n = {s.c3, c_s, 2.0 * s.d3};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(n.c3), "+v"(n.cs), "+v"(n.d3x2));   // (vector registers from here on: not rematerialised per use)
+#endif
+  return n;
+}
+__device__ __forceinline__ void newton_eval(const Salt &s, const NewtonConsts &n, double A0, double LS, double T_0, double &T_new, bool &more, bool &ok) {
+  const double sbf = T_0 * fma_c(T_0, __builtin_fma(T_0, s.c4, n.c3), s.c2);      // (fma_c: the addend from a scalar register pair)
   const double sb2 = sbf * sbf;
-  const double A = __builtin_fma(T_0, __builtin_fma(T_0, 0.5 * c_s_beta, c_s), A0);
-  const double B = __builtin_fma(c_s_beta, T_0, c_s);
+  const double A = __builtin_fma(T_0, __builtin_fma(T_0, 0.5 * c_s_beta, n.cs), A0);
+  const double B = __builtin_fma(c_s_beta, T_0, n.cs);
   const double num = __builtin_fma(A, sb2, LS * sbf);
   const double Tc = max_c(T_0, -20.0);                       // derivative-only clamp below -20 C, mo_thermo_functions.f90:408-412
-  const double dd = __builtin_fma(Tc, __builtin_fma(Tc, 3.0 * s.d4, 2.0 * s.d3), s.d2);
+  const double dd = fma_c(Tc, __builtin_fma(Tc, 3.0 * s.d4, n.d3x2), s.d2);
   const double den = __builtin_fma(B, sb2, -(LS * dd));
   T_new = T_0 - quot(num, den);
   more = fabs(num) > sb2;
@@ -402,7 +417,7 @@ __device__ __forceinline__ bool newton_step(const Salt &s, double H, double S_bu
   {
     bool more, ok;
     double Tn;
-    newton_eval(s, -latent_heat - H, latent_heat * S_bu, T_0, Tn, more, ok);
+    newton_eval(s, newton_consts(s), -latent_heat - H, latent_heat * S_bu, T_0, Tn, more, ok);
     if (ok) { T_new = Tn; return more; }
   }
   const double sb = S_br_poly(s, T_0);
@@ -474,16 +489,18 @@ __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, 
   const double Tl = T_liquid(H);
   const bool mushy = S_br_clamped(s, Tl, S_bu) > S_bu && S_bu > 0.001;
   const double A0 = -latent_heat - H, LS = latent_heat * S_bu;
+  const NewtonConsts nc = newton_consts(s);
   double T;
   bool more, ok;
-  newton_eval(s, A0, LS, T_in, T, more, ok);
+  newton_eval(s, nc, A0, LS, T_in, T, more, ok);
   bool odd = !mushy || !ok;
   more = more && !odd;
   int i = 0;
+  ISA_MARK("NEWTON_LOOP");
   while (__ballot(more) != 0ull) {
     double Tn;
     bool m2, ok2;
-    newton_eval(s, A0, LS, T, Tn, m2, ok2);
+    newton_eval(s, nc, A0, LS, T, Tn, m2, ok2);
     if (more && (T > 0.0 || T < -200.0 || !ok2)) odd = true;     // (the test is on the iterate the evaluation started from)
 #if SAMSIM_STAMPS == 2
     if (evals && more) *evals += 1;
@@ -492,6 +509,7 @@ __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, 
     more = more && m2 && !odd;
     if (++i == 260) { if (more) odd = true; break; }
   }
+  ISA_MARK("NEWTON_LOOP_END");
   double phi = 1.0 - quot(S_bu, S_br_clamped(s, T, S_bu));
   int rc = 0;
   if (odd) {
@@ -585,6 +603,8 @@ struct Ctx {
   gdouble *out_lay, *out_scal;
   gdouble *scal;  // [SAMSIM_NSCAL][ncol] scalar block: slots that are not carried in registers (fl_rest) are read / written in place
   gint32 *out_n_active;
+  gint32 *err_layer;                                   // [ncol] layer and step of a column's STOP (written once, when it stops)
+  __attribute__((address_space(1))) long long *err_step;
   long long out_col0, out_ncols;
   Salt salt;
   double p17, p14, tf_c3;
@@ -974,7 +994,9 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
         LAYU(SAMSIM_A_RAY, k) = ray;
       } else if (k == 1 || x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // wave-uniform k, see Ctx::rflag (row 1 always: ray_row_valid)
         LAYU(SAMSIM_A_RAY, k) = ray;
-        if (wave_leader()) x.rflag[(k - 1) >> 6] |= 1ull << ((k - 1) & 63);
+        // (every executing lane reads the word, sets the same bit and writes the same value back -- two LDS instructions in
+        // lock-step, no leader to elect: the lane number a leader test compares with was one more value carried through the loop)
+        x.rflag[(k - 1) >> 6] = x.rflag[(k - 1) >> 6] | (1ull << ((k - 1) & 63));
       }
     }
   }
@@ -1559,10 +1581,12 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // iteration of lead, a second finished layer -- 18 registers -- held for the sake of a test that is reached in a fifth of the
   // layers.  That test now forms S_br(j+1) from the request buffer on demand.)
   struct Ld { double T, S_abs, m, H_abs, ray; };
-  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, thick, rth, ray, H; };
-  const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-  // 1/thick of the two thicknesses of the grid rule, once per sweep (this sweep only runs on regular columns), and of layer 1
-  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
+  struct Raw { double T, S_abs, m, S_bu, S_br, H_abs, ray, H; };
+  // This sweep only runs on columns that follow the grid rule: the interior layers are walked in three stretches (top block,
+  // elastic block, bottom block), inside each of which thick and 1/thick are one value -- the loop body neither loads nor selects
+  // them (round 2 formed them per layer from the configuration, which the compiler re-read from memory inside the loop).  The
+  // two values are formed where a stretch begins (the elastic block's thickness is one load per sweep), so that nothing but the
+  // current pair is carried through the loop.
   auto load_ld = [&](int j) -> Ld {
     Ld r;
     r.T = LAYU(SAMSIM_A_T, j);
@@ -1577,9 +1601,6 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   auto finish = [&](const Ld &l, int j) -> Raw {
     Raw r;
     r.T = l.T; r.S_abs = l.S_abs; r.m = l.m; r.H_abs = l.H_abs; r.ray = l.ray;
-    const bool mid = (j > g.n_top && j <= g.n_top + g.n_middle);
-    r.thick = (j >= 2) ? (mid ? th_mid : g.thick_0) : LAYU(SAMSIM_A_THICK, 1);   // (fused path: regular columns only)
-    r.rth = (j >= 2) ? (mid ? rth_mid : rth_0) : recip(r.thick);
     per_mass(r.S_abs, r.H_abs, r.m, r.S_bu, r.H);   // as the first sweep formed them
     r.S_br = S_br_clamped(s, r.T, r.S_bu);
     return r;
@@ -1592,7 +1613,10 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   // (SA, mA: salt and mass right after A(j).  Their quotient, the refreshed bulk salinity of mo_grotz.f90:333-335, is only
   // read where brine actually moves -- the drainage test of B(j) and the return-flow transfers of C -- so it is formed there:
   // same operands, same quotient, one division less in the nine layers out of ten that do not drain)
-  struct Lay { double T, SA, mA, S_abs, H_abs, m, flup; };
+  // (ch: brine moved in or out of the layer -- expulsion, drainage, return flow -- so its mass or salt changed.  In winter that
+  // holds in a quarter of the layer rows of a wave; elsewhere m and S_abs would be stored with the bits they were loaded with,
+  // and the stores are skipped: 16 of the 88 bytes a layer-cell moves per step.)
+  struct Lay { double T, SA, mA, S_abs, H_abs, m, flup; bool ch; };
 
   double flm_j = 0.0;                                  // fl_m(j) of expulsion_flux
   double T_up = 0.0, S_br_up = 0.0, S_abs_up = 0.0;    // layer j-1 as mass_transfer #1 sees it
@@ -1600,18 +1624,18 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   const int N = c.N;
   Raw raw = finish(load_ld(1), 1);
   Ld ahead = load_ld(2), ahead2 = ahead;               // layers j+1 and j+2 (nlayer >= 3, samsim_create)
-  Lay prev = {0, 0, 1, 0, 0, 0, 0};                    // layer j-1 after A and B, waiting for C
+  Lay prev = {0, 0, 1, 0, 0, 0, 0, true};              // layer j-1 after A and B, waiting for C
   double flup_pp = 0.0;                                // fl_up(j-2)
   // One layer of the sweep: A(j), B(j), C(j-1).  LAST = the column's bottom layer N_active, which differs from lane to lane: it
   // runs after the loop (once per wave, every lane with its own j), so that the loop body -- the interior layers -- carries
   // neither the bottom-layer work (gas -> ocean water, the bottom turbulence with its exp and two pow) nor its registers.
-  auto layer = [&](const int j, const Ld &below, auto last_tag, auto first_tag) {   // below: the request buffer that holds layer j+1
+  auto layer = [&](const int j, const Ld &below, const double thick, const double rth, auto last_tag, auto first_tag) {   // below: the request buffer that holds layer j+1
     constexpr bool LAST = decltype(last_tag)::value, FIRST = decltype(first_tag)::value;
+    if (!LAST && !FIRST) { ISA_MARK("D_LAYER_A"); }
     // ---- A(j)
-    const double thick = raw.thick;
     // Expulsion of the first sweep (mo_grotz.f90:306), re-evaluated from its inputs phi, thick, m
     double H_abs = raw.H_abs;
-    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, raw.rth);
+    const Expelled ex = expulsion(phi_from_T(s, raw.H, raw.S_bu, raw.S_br), thick, raw.m, rth);
     const double V_ex = ex.V_ex;
     double psi_g = ex.psi_g, m = raw.m, S_abs = raw.S_abs;
     const double T = raw.T, S_br = raw.S_br;
@@ -1644,6 +1668,13 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       H_abs = H_abs - flm_j * T_up * c_l;
       S_abs = S_abs - dmax(flm_j * S_br_up, -S_abs_up);
     }
+    bool ch = LAST || (flm_next < 0.0) || (flm_j < 0.0);
+#if SAMSIM_STAMPS == 2
+    if (!LAST && !FIRST) {   // rows of the interior in which the expulsion moves no brine in any column of the wave (m and S_abs keep their bits)
+      ST_COUNT(CT_ROWS, 1);
+      if (__ballot(flm_next < 0.0 || flm_j < 0.0) == 0ull) ST_COUNT(CT_ROWS_STILL, 1);
+    }
+#endif
     const double SA = S_abs, mA = m;     // S_bu = SA / mA: refreshed bulk salinity, mo_grotz.f90:333-335 (formed where it is read)
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_j = flm_next;
@@ -1659,7 +1690,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       const int rcc = snow_coupling_core<K>(c, x, H_abs, m, S_bu1, Tl, phi1);
       LAYU(SAMSIM_A_T, 1) = Tl;
       LAYU(SAMSIM_A_PHI, 1) = phi1;
-      if (rcc && !c.status) { c.status = rcc; c.err_step = c.step + 1; c.err_layer = 1; }
+      if (rcc && !c.status) { c.status = rcc; x.err_step[c.col] = c.step + 1; x.err_layer[c.col] = 1; }
     }
     if (LAST) {
       if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
@@ -1674,6 +1705,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       }
     }
     // ---- B(j)
+    if (!LAST && !FIRST) { ISA_MARK("D_LAYER_B"); }
     ST_MARK(ST_D_A);
     sum_before += S_abs;
     double flup = cum;
@@ -1695,19 +1727,23 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
           heat_loss = heat_loss + flux * c_l * Tl;
           cum = cum + flux;
           flup = dmin(cum, psi_l * rho_l * thick);
+          ch = true;
         }
       }
     }
     sum_after += S_abs;
+    if (!LAST && !FIRST) { ISA_MARK("D_LAYER_C"); }
     // ---- C(j-1): layer j-1 receives from layer j (fl_m(j) = fl_up(j-1)) and gives to j-2 (fl_m(j-1) = fl_up(j-2))
     if (j > 1) {
       if (prev.flup > 0.0) {
         prev.H_abs = prev.H_abs + prev.flup * T * c_l;
         prev.S_abs = prev.S_abs + dmin(prev.flup * S_br_clamped(s, T, quot(SA, mA)), S_abs);
+        prev.ch = true;
       }
       if (flup_pp > 0.0) {
         prev.H_abs = prev.H_abs - flup_pp * prev.T * c_l;
         prev.S_abs = prev.S_abs - dmin(flup_pp * S_br_clamped(s, prev.T, quot(prev.SA, prev.mA)), prev.S_abs);
+        prev.ch = true;
       }
       // The brine transports of layer j-1 are complete: what the reference does next to its enthalpy is the explicit conductive
       // update of sub_heat_fluxes, H_abs(k) += (fl_Q(k+1) - fl_Q(k))*dt, then += fl_rad(N_active)*dt (mo_heat_fluxes.f90:277-285:
@@ -1720,22 +1756,26 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
         prev.H_abs = prev.H_abs + c.frad * dt;
         esum += H_b - prev.H_abs;
       }
-      LAYU(SAMSIM_A_M, j - 1) = prev.m;
-      LAYU(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
+      if (__ballot(prev.ch) != 0ull) {   // (wave-uniform: a row is stored for all its columns or for none)
+        LAYU(SAMSIM_A_M, j - 1) = prev.m;
+        LAYU(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
+      }
       LAYU(SAMSIM_A_H_ABS, j - 1) = prev.H_abs;
       minS = dmin(minS, prev.S_abs);
       flup_pp = prev.flup;
     }
     hr_up = hr; flq_up = flq;
-    prev.T = Tl; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup;
+    prev.T = Tl; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup; prev.ch = ch;
+    if (!LAST && !FIRST) { ISA_MARK("D_LAYER_END"); }
     ST_MARK(ST_D_B);
   };
   const int jmax = wave_max(Na);
   auto request = [&](const int j) { ahead2 = load_ld(j + 2 <= N ? j + 2 : N); };      // top of iteration j: layer j+2
   auto advance = [&](const int j) { raw = finish(ahead, j + 1); ahead = ahead2; };      // end of iteration j: layer j+1 becomes current
   // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
-  if (1 < Na) { request(1); layer(1, ahead, std::false_type{}, std::true_type{}); advance(1); }
-  if (2 < Na) { request(2); layer(2, ahead, std::false_type{}, std::false_type{}); advance(2); }
+  const double thick1 = LAYU(SAMSIM_A_THICK, 1);
+  if (1 < Na) { request(1); layer(1, ahead, thick1, recip(thick1), std::false_type{}, std::true_type{}); advance(1); }
+  if (2 < Na) { request(2); layer(2, ahead, g.thick_0, recip(g.thick_0), std::false_type{}, std::false_type{}); advance(2); }   // (N_top >= 3: samsim_create)
   if (late_rad) {   // (see the head of the routine; nothing above reads fl_rad, the albedo or the short-wave flux)
     const double beer0 = radiation_header<K>(c, x, time, tc);
     c.frad = 0.0;
@@ -1769,36 +1809,47 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   c.psi_full = store_psi;
   // The interior layers 3 <= j < N_active, two per trip: the two request buffers swap roles from one layer to the next, so with
   // both layers in one loop body no buffer is copied into the other (and the hand-over of layer j to C(j) of the next layer is a
-  // renaming): the single-layer loop spent 35 of its 265 vector instructions on those copies.
+  // renaming): the single-layer loop spent 35 of its 265 vector instructions on those copies.  A stretch with an odd number of
+  // layers ends with one single-layer step that does copy its buffer (at most three per sweep).
   {
+    const int b0 = g.n_top, b1 = g.n_top + g.n_middle;
     int j = 3;
-    for (; j + 1 < jmax; j += 2) {
-      ISA_MARK("D_ITER_BEGIN");
-      ST_MARK(ST_DFUSED);
-      if (j + 1 < Na) {                                  // both layers are interior layers of this column: one straight-line body
-        ST_COUNT(CT_DOWN_TRIPS, 2);
-        ahead2 = load_ld(j + 2 <= N ? j + 2 : N);        // layer j+2 -> second buffer
-        layer(j, ahead, std::false_type{}, std::false_type{});
-        raw = finish(ahead, j + 1);
-        ahead = load_ld(j + 3 <= N ? j + 3 : N);         // layer j+3 -> first buffer
-        layer(j + 1, ahead2, std::false_type{}, std::false_type{});
-        raw = finish(ahead2, j + 2);
+    for (int stretch = 0; stretch < 3; ++stretch) {
+      const int hi_s = stretch == 0 ? b0 : (stretch == 1 ? b1 : N);
+      const int hi = hi_s < jmax - 1 ? hi_s : jmax - 1;           // last interior layer of the stretch in the longest column of the wave
+      const double th_s = stretch == 1 ? LAYU(SAMSIM_A_THICK, g.n_top + 1) : g.thick_0, rth_s = recip(th_s);
+      for (; j + 1 <= hi; j += 2) {
+        ISA_MARK("D_ITER_BEGIN");
+        ST_MARK(ST_DFUSED);
+        if (j + 1 < Na) {                                  // both layers are interior layers of this column: one straight-line body
+          ST_COUNT(CT_DOWN_TRIPS, 2);
+          ahead2 = load_ld(j + 2 <= N ? j + 2 : N);        // layer j+2 -> second buffer
+          layer(j, ahead, th_s, rth_s, std::false_type{}, std::false_type{});
+          raw = finish(ahead, j + 1);
+          ahead = load_ld(j + 3 <= N ? j + 3 : N);         // layer j+3 -> first buffer
+          layer(j + 1, ahead2, th_s, rth_s, std::false_type{}, std::false_type{});
+          raw = finish(ahead2, j + 2);
+        } else if (j < Na) {                               // layer j is the column's last interior layer
+          ST_COUNT(CT_DOWN_TRIPS, 1);
+          ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
+          layer(j, ahead, th_s, rth_s, std::false_type{}, std::false_type{});
+          raw = finish(ahead, j + 1);
+        }
+        ISA_MARK("D_ITER_END");
       }
-      else if (j < Na) {                               // layer j is the column's last interior layer
-        ST_COUNT(CT_DOWN_TRIPS, 1);
-        ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
-        layer(j, ahead, std::false_type{}, std::false_type{});
-        raw = finish(ahead, j + 1);
+      if (j <= hi) {                                       // odd number of layers in this stretch
+        if (j < Na) {
+          ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
+          layer(j, ahead, th_s, rth_s, std::false_type{}, std::false_type{});
+          raw = finish(ahead, j + 1);
+          ahead = ahead2;
+        }
+        ++j;
       }
-      ISA_MARK("D_ITER_END");
-    }
-    if (j < jmax && j < Na) {                            // odd number of interior layers in the longest column of the wave
-      ahead2 = load_ld(j + 2 <= N ? j + 2 : N);
-      layer(j, ahead, std::false_type{}, std::false_type{});
-      raw = finish(ahead, j + 1);
     }
   }
-  layer(Na, ahead, std::true_type{}, std::false_type{});                  // the bottom layer (this sweep only runs with N_active >= 2)
+  const double thick_Na = (Na > g.n_top && Na <= g.n_top + g.n_middle) ? LAYU(SAMSIM_A_THICK, g.n_top + 1) : g.thick_0;
+  layer(Na, ahead, thick_Na, recip(thick_Na), std::true_type{}, std::false_type{});   // the bottom layer (this sweep only runs with N_active >= 2)
   // ---- C(Na): the ocean below (ghost cell of mass_transfer, mo_mass.f90:70-72)
   if (prev.flup > 0.0) {
     prev.H_abs = prev.H_abs + prev.flup * g.T_bottom * c_l;
@@ -1982,10 +2033,8 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // wave with a hand-made column loads the array with the other operands and forms 1/thick per layer.
   struct UL { double th, H, m, S; };
   const bool regular_wave = __ballot((c.flags & COLF_REGULAR) == 0) == 0ull;
-  const double th_mid = LAYU(SAMSIM_A_THICK, g.n_top + 1);
-  const double rth_0 = recip(g.thick_0), rth_mid = recip(th_mid);
   UL cur, nxt, nn;
-  bool alive = true;
+  bool alive = true, neg_salt = false;
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
   // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
   // thin-snow coupling (up to 200 getT pairs) nor its registers.
@@ -2039,10 +2088,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     if (store_phi || TOP || k >= Na - 1) LAYU(SAMSIM_A_PHI, k) = phi;
     if (!TOP) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
-      if (S_abs < 0.0) {
-        // a clamped salt mass changes S_bu and therefore T: leave this column to the full sweep
-        c.flags |= COLF_DIRTY;
-      }
+      // (a clamped salt mass changes S_bu and therefore T: such a column is left to the full sweep, flagged after the loop -- a
+      // read-modify-write of the column's flag word inside the loop is one more value for the allocator to spill there)
+      neg_salt = neg_salt || (S_abs < 0.0);
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, th_k, rth_k, r, true);
     }
     ST_MARK(ST_U_TAIL);
@@ -2052,18 +2100,29 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   auto load4 = [&](int j) -> UL { UL u = load3(j); u.th = LAYU(SAMSIM_A_THICK, j); return u; };
   if (regular_wave) {
     cur = load3(Na); nxt = load3(Na >= 2 ? Na - 1 : 1); nn = nxt;   // layers k, k-1, k-2
+#if SAMSIM_UAHEAD == 3
+    nn = load3(Na >= 3 ? Na - 2 : 1);
+    UL n3 = nn;                                                      // layer k-3
+#endif
     const int b0 = g.n_top, b1 = g.n_top + g.n_middle;
     int k = kmax;
     for (int stretch = 0; stretch < 3; ++stretch) {
       const int klo = stretch == 0 ? b1 + 1 : (stretch == 1 ? b0 + 1 : 2);
-      const double th_s = stretch == 1 ? th_mid : g.thick_0, rth_s = stretch == 1 ? rth_mid : rth_0;
+      // (formed where the stretch begins -- the elastic block's thickness is one load per sweep -- so that only this pair is carried)
+      const double th_s = stretch == 1 ? LAYU(SAMSIM_A_THICK, g.n_top + 1) : g.thick_0, rth_s = recip(th_s);
       for (; k >= klo; --k) {
         ISA_MARK("U_ITER_BEGIN");
         ST_MARK(ST_UP);
         if (k > Na) continue;
+#if SAMSIM_UAHEAD == 3
+        n3 = load3(k >= 4 ? k - 3 : 1);
+        body(k, th_s, rth_s, std::false_type{});
+        cur = nxt; nxt = nn; nn = n3;
+#else
         nn = load3(k >= 3 ? k - 2 : 1);
         body(k, th_s, rth_s, std::false_type{});
         cur = nxt; nxt = nn;
+#endif
         ISA_MARK("U_ITER_END");
       }
     }
@@ -2077,6 +2136,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     }
   }
   __builtin_amdgcn_wave_barrier();   // the row flags are complete: the next readers are the down sweeps of the next step
+  if (neg_salt) c.flags |= COLF_DIRTY;
   body(1, LAYU(SAMSIM_A_THICK, 1), 0.0, std::true_type{});
   if (!alive) return;
   // hand-over block for prologue_top_layer of the next step
@@ -3115,6 +3175,7 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   x.f_sw = (gcdouble *)f_sw; x.f_lw = (gcdouble *)f_lw; x.f_T2m = (gcdouble *)f_T2m; x.f_precip = (gcdouble *)f_precip;
   x.out_lay = (gdouble *)out_lay; x.out_scal = (gdouble *)out_scal; x.out_n_active = (gint32 *)out_n_active;
   x.scal = (gdouble *)scal;
+  x.err_layer = (gint32 *)err_layer; x.err_step = (__attribute__((address_space(1))) long long *)err_step;
   x.bgc = (gdouble *)bgc; x.bgc_bot = (gdouble *)bgc_bot; x.bfl = (gdouble *)bfl;
   x.out_bgc = (gdouble *)out_bgc; x.out_bgc_bot = (gdouble *)out_bgc_bot;
   x.n_bgc = K::bgc ? p.n_bgc : 0; x.bgc_total0 = p.bgc_total0;
@@ -3147,8 +3208,6 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
   c.N = p.cfg.nlayer;
   c.Na = n_active[col];
   c.status = status[col];
-  c.err_layer = err_layer[col];
-  c.err_step = err_step[col];
   c.frad = 0.0; c.neg_psi = false; c.buoy_s = 0.0; c.buoy_g = 0.0; c.psi_l_top = 1.0;
   c.flags = flags[col];
   c.spec = (gdouble *)spec;
@@ -3202,20 +3261,29 @@ __global__ void __launch_bounds__(SAMSIM_BLOCK, SAMSIM_WAVES) samsim_step_kernel
       // per-lane addresses, keeps them for the whole launch and, having no registers for them, spills them at the start and
       // reloads one from scratch memory (= HBM) at every use.  Passing the index through an empty asm makes them values of the
       // step: each is formed where it is used (two or three vector instructions) and nothing is carried.
-      long long col_step = col;
-      asm volatile("" : "+v"(c.col), "+v"(c.coff), "+v"(c.lcoff), "+v"(col_step));
+      // (Round 2 passed the stored index through an empty asm; the allocator then kept it in scratch memory and reloaded it at every
+      // step.  Now the lane number is read off the hardware -- two instructions, no memory -- and the index rebuilt from it.)
+      unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(lane));
+      c.lcoff = lane * 8u;
+      c.col = (unsigned)(blk * SAMSIM_BLOCK) + lane;
+      c.coff = c.col * 8u;
+      const long long col_step = blk * SAMSIM_BLOCK + (long long)lane;
       column_step<K>(c, x, col_step, time, tc, out_step, next_out, s + 1 == p.nsteps);
     }
     time = time + p.cfg.dt;
     step = step + 1;
   }
 
-  n_active[col] = c.Na;
-  flags[col] = c.flags;
-  status[col] = c.status;
-  err_layer[col] = c.err_layer;
-  err_step[col] = c.err_step;
-  work[col] += work_done;
+  // (the column index and the scalar block's address are rebuilt from the lane number rather than carried through the time loop)
+  unsigned lane_end = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane_end));
+  const long long col_end = blk * SAMSIM_BLOCK + (long long)lane_end;
+  n_active[col_end] = c.Na;
+  flags[col_end] = c.flags;
+  status[col_end] = c.status;
+  work[col_end] += work_done;
+  sc = scal + col_end;
 #define SSTORE(field, idx) sc[(size_t)(idx) * nc] = c.field
   SSTORE(fl_q_bottom, SAMSIM_S_FL_Q_BOTTOM);
 #undef SSTORE

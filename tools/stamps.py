@@ -20,7 +20,7 @@ NAMES = ["t_prologue", "t_down_fused", "t_down_unfused", "t_surface", "t_up", "t
          "wave_steps", "fused", "unfused", "up_trips", "newton_wave", "newton_lane", "lanes", "down_trips", "drain_wave",
          "drain_lane", "dirty", "lanes_coupling", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC",
          "lanes_flood_possible", "lanes_irregular", "lanes_dirty", "lanes_unfused", "lanes_flush3", "lanes_regrid", "lanes_freeboard",
-         "lanes_refill_psi"] + [f"slot{i}" for i in range(33, 48)]
+         "lanes_refill_psi", "down_rows_interior", "down_rows_without_expulsion"] + [f"slot{i}" for i in range(35, 48)]
 
 
 def main():
