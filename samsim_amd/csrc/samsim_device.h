@@ -38,7 +38,15 @@ enum dev_spec {
   SP_BUOY_S, SP_MIN_PSI_S,                  // partial SUM(psi_s*thick), MIN(psi_s) over layers 2..N_active
   // from the down sweep of a step to func_freeboard later in the same step (written where the sweep stores the volume-fraction rows):
   SP_FB_A2, SP_FB_G2,                       // SUM(psi_s*thick), SUM(psi_g*thick) over layers 2..N_active, top -> bottom
-  DEV_NSPEC
+  // from the first sweep of a step to flood / refresh_ray_top of the same step (written only where the snow load makes flooding
+  // possible): harmonic-mean permeability of the whole column and its total thickness, as mo_flood.f90:66-80 forms them
+  SP_FL_HP, SP_FL_SALL,
+  DEV_NSPEC,
+  // Once a column has been flooded in the fused order (column_step) the scan rows above have served; until the up sweep rewrites
+  // them they carry the flooded top layer from the flooding block to the down sweep (COLF_FLOODED), and SP_FL_HP / SP_FL_SALL the
+  // bottom layer's increments of an instant flooding (COLF_FLOOD_DEEP): memory instead of six values held across the radiation
+  // header and the Beer-law pass.
+  SP_FLD_S1 = SP_MINP, SP_FLD_H1 = SP_STP, SP_FLD_M1 = SP_ST, SP_FLD_TH1_BEFORE = SP_BOT
 };
 
 // rows of the tracer flux block: what the reference collects in fl_brine_bgc(N+1, N+1) (mo_data.f90:183)
@@ -54,6 +62,8 @@ enum dev_bgc_flux {
 // per-column flag bits
 #define COLF_DIRTY 1    // prognostic layers changed since the last up sweep: the next step runs the full S1 sweep
 #define COLF_RESTART 2  // first step after samsim_set_state: RAY holds the previous Rayleigh numbers
+#define COLF_FLOODED 32     // (within a step) the fused order flooded this column: the flooded top layer waits in the hand-over block
+#define COLF_FLOOD_DEEP 16  // (within a step) the fused order flooded this column below neg_free: the bottom layer's increments wait in the hand-over block
 #define COLF_REGRID 8   // layer_dynamics changed the grid in the previous step: the full first sweep checks the thickness rule again
 #define COLF_REGULAR 4  // the thicknesses of layers 2..N_active follow the grid rule (thick_0, and one common value in the middle
                         // block): the sweeps take them from two loaded values instead of the array (checked by the full first

@@ -1002,6 +1002,21 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
   }
 }
 
+// What flooding needs of the whole column (mo_flood.f90:66-80: the harmonic-mean permeability SUM(thick) / SUM(thick/perm) with the
+// bottom layer's solid part, and the total thickness) is what the first sweep's scan holds once layer 1 is in: instead of walking
+// the column twice more (flood, then refresh_ray_top after flooding has changed thick(1); a power per layer each), the sweep leaves
+// the two numbers in the hand-over block where the snow load makes flooding possible -- and the scan WITHOUT layer 1, which
+// refresh_ray_top completes with the flooded top layer.  (sums bottom -> top where the reference's run top -> bottom: round-off)
+template <class K>
+__device__ __forceinline__ void flood_handover(Col &c, const Ctx &x, const RayScan &all, const RayScan &below_top, double thick_bottom) {
+  const samsim_config &g = x.p->cfg;
+  if (!(CFG(flood_flag) > 1 && c.Na > 1 && CL(m_snow) > all.buoy_s * (rho_l - rho_s))) return;   // (= flood_possible of column_step)
+  SPEC(SP_FL_HP) = quot(all.st + all.bot, all.stp + all.botterm);
+  SPEC(SP_FL_SALL) = all.st + thick_bottom;
+  SPEC(SP_MINP) = below_top.minp; SPEC(SP_STP) = below_top.stp; SPEC(SP_ST) = below_top.st;
+  SPEC(SP_BOT) = below_top.bot; SPEC(SP_BOTTERM) = below_top.botterm; SPEC(SP_SBR_BOT) = below_top.S_br_bot;
+}
+
 // all_phi: the solid fractions of every layer go to their array (an output point follows); otherwise only where something reads them
 // before the up sweep rewrites them (layer 1, the bottom two layers: thin-snow coupling, regrid trigger).  whole_wave: every column
 // of the wave runs this sweep (the normal state of a melt season, when every column flushes in every step): then the Rayleigh rows
@@ -1013,8 +1028,10 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x, bool all_phi, 
   const int Na = c.Na;
   const bool do_ray = (CFG(grav_flag) >= 2 && Na > 1);
   double T_test = g.T_bottom;
-  RayScan r;
+  RayScan r, r_below_top;
   ray_scan_init(r);
+  r_below_top = r;
+  double thick_bottom = 0.0;
   int rc = 0, rc_layer = 0;
   if (do_ray && Na <= c.N - 1 && (!whole_wave || x.ray_rows_all)) LAYU(SAMSIM_A_RAY, Na) = 0.0;
   if (whole_wave) {
@@ -1060,11 +1077,14 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x, bool all_phi, 
       // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
       LAYU(SAMSIM_A_T, k) = T;
       if (all_phi || k == 1 || k >= Na - 1) LAYU(SAMSIM_A_PHI, k) = phi;
+      if (k == 1) r_below_top = r;                                   // the scan over layers N_active..2 (flood_handover)
+      if (k == Na) thick_bottom = thick;
       s1_layer<K>(c, x, k, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r, whole_wave);
     }
   };
   if (check_wave) run(std::true_type{}); else run(std::false_type{});
   if (whole_wave) { __builtin_amdgcn_wave_barrier(); c.ray_all = false; }   // the rows that hold a value are the flagged ones
+  if (do_ray) flood_handover<K>(c, x, r, r_below_top, thick_bottom);
   c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   c.flags = regular ? (c.flags | COLF_REGULAR) : (c.flags & ~COLF_REGULAR);
@@ -1082,6 +1102,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   r.minp = SPEC(SP_MINP); r.stp = SPEC(SP_STP); r.st = SPEC(SP_ST);
   r.bot = SPEC(SP_BOT); r.botterm = SPEC(SP_BOTTERM); r.perm_bot = SPEC(SP_PERM_BOT);
   r.S_br_bot = SPEC(SP_SBR_BOT); r.buoy_s = SPEC(SP_BUOY_S); r.min_psi_s = SPEC(SP_MIN_PSI_S);
+  const RayScan r_below_top = r;
   const double H_abs = LAY(SAMSIM_A_H_ABS, 1), m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1);
   double S_abs = LAY(SAMSIM_A_S_ABS, 1);
   if (S_abs < 0.0) { S_abs = 0.0; LAY(SAMSIM_A_S_ABS, 1) = S_abs; }
@@ -1094,6 +1115,10 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
   s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r);
+  if (do_ray && CFG(flood_flag) > 1 && CL(m_snow) > r.buoy_s * (rho_l - rho_s)) {   // (flood_handover's own test: the thickness of the bottom layer is only formed where it is used)
+    THICK_RULE_INIT(tr);
+    flood_handover<K>(c, x, r, r_below_top, THICK_AT(tr, Na));
+  }
   c.neg_psi = r.min_psi_s < 0.0;
   c.buoy_s = r.buoy_s;
   if (rc) STOPC(rc, 1);
@@ -1103,8 +1128,16 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
 // expulsion_flux (mo_mass.f90:112-136): downward brine flux recurrence, m and psi_g update.  mass_transfer
 // (mo_mass.f90:53-96) with these fluxes (all <= 0: brine only moves down) needs the layer above only.  Then the
 // S_bu refresh of mo_grotz.f90:333-335.  mass_transfer is skipped on the first step (mo_grotz.f90:313).
-template <class K>
-__device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
+// DRY: nothing is stored -- the sweep only tells what flooding needs to know before the fused down sweep runs (column_step): the
+// gas-filled volume of the column after expulsion_flux (for the freeboard) and the top and bottom layers as brine expulsion and its
+// mass_transfer leave them (flooding moves water between exactly these two and the snow).
+struct ExpelledEnds {
+  double S1, H1, m1, psi_l1, S_br1;    // layer 1 after expulsion + mass_transfer; its liquid fraction and brine salinity of the first sweep
+  double SN, HN, mN, TN, psi_gN;       // layer N_active likewise (before the gas -> ocean water replacement)
+  double buoy_g;                       // SUM(psi_g*thick) after expulsion_flux
+};
+template <class K, bool DRY = false>
+__device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x, ExpelledEnds *ends = nullptr) {
   const int Na = c.Na;
   const bool transfer = (c.step + 1 != 1);
   double flm_k = 0.0;  // fl_m(k)
@@ -1148,15 +1181,19 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
     }
     if (psi_g > 0.0) buoy_g += psi_g * thick;
     if (k >= 2) { fb_a2 += ex.psi_s * thick; fb_g2 += psi_g * thick; }
-    LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
-    LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
-    LAY(SAMSIM_A_PSI_G, k) = psi_g;
+    if (!DRY) {
+      LAY(SAMSIM_A_PSI_S, k) = ex.psi_s;
+      LAY(SAMSIM_A_PSI_L, k) = ex.psi_l;
+      LAY(SAMSIM_A_PSI_G, k) = psi_g;
+    }
     m = m + flm_next - flm_k;
-    LAY(SAMSIM_A_M, k) = m;
-    if (HAS_BGC) BFL(BFL_E, k) = transfer ? -flm_next : 0.0;
-    LAY(SAMSIM_A_S_BR, k) = S_br;
+    if (!DRY) {
+      LAY(SAMSIM_A_M, k) = m;
+      if (HAS_BGC) BFL(BFL_E, k) = transfer ? -flm_next : 0.0;
+      LAY(SAMSIM_A_S_BR, k) = S_br;
+    }
+    double H_abs = H_abs_in;
     if (transfer) {
-      double H_abs = H_abs_in;
       bool ch = false;
       if (flm_next < 0.0) {
         H_abs = H_abs + flm_next * T * c_l;
@@ -1168,17 +1205,22 @@ __device__ RARE void sweep_expulsion_transfer(Col &c, const Ctx &x) {
         S_abs = S_abs - dmax(flm_k * S_br_up, -S_abs_up);
         ch = true;
       }
-      if (ch) {
+      if (ch && !DRY) {
         LAY(SAMSIM_A_H_ABS, k) = H_abs;
         LAY(SAMSIM_A_S_ABS, k) = S_abs;
       }
     }
-    LAY(SAMSIM_A_S_BU, k) = S_abs / m;
+    if (!DRY) LAY(SAMSIM_A_S_BU, k) = S_abs / m;
+    if (DRY) {
+      if (k == 1) { ends->S1 = S_abs; ends->H1 = H_abs; ends->m1 = m; ends->psi_l1 = ex.psi_l; ends->S_br1 = S_br; }
+      if (k == Na) { ends->SN = S_abs; ends->HN = H_abs; ends->mN = m; ends->TN = T; ends->psi_gN = psi_g; }
+    }
     T_up = T; S_br_up = S_br; S_abs_up = S_abs;
     flm_k = flm_next;
     }
     }
   }
+  if (DRY) { ends->buoy_g = buoy_g; return; }
   c.buoy_g = buoy_g;
   SPEC(SP_FB_A2) = fb_a2; SPEC(SP_FB_G2) = fb_g2;
 }
@@ -1218,30 +1260,19 @@ __device__ RARE void vital_signs(Col &c, const Ctx &x) {
 }
 
 // ---------------------------------------------------------------- flood, mo_flood.f90:55-151
+// The arithmetic of flood on the two layers it touches, held in registers: layer 1 (S1, H1, m1, th1) and layer N_active (SN, HN, mN,
+// TN: read; its increments incS, incH are returned, applied where `deep` -- the instant flooding below neg_free), and the snow
+// (in LDS).  flood() below runs it on the arrays (the unfused order); the fused order on what its dry run of the expulsion returned.
+struct FloodEnds { double S1, H1, m1, th1, SN, HN, mN, TN, incS, incH; bool deep; };
 template <class K>
-__device__ RARE void flood(Col &c, const Ctx &x) {
+__device__ __forceinline__ double flood_core(Col &c, const Ctx &x, double hp, double sall, FloodEnds &e) {
   const samsim_config &g = x.p->cfg;
-  const int Na = c.Na;
-  double hp = 0.0, sth = 0.0;
-  for (int k = 1; k <= Na - 1; ++k) {
-    const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, k));
-    hp = hp + thick / perm;
-    sth += thick;
-  }
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
-  const double permN = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, Na));
-  hp = hp + (thN * psN / psi_s_min) / permN;
-  hp = (sth + thN * psN / psi_s_min) / hp;
-  const double sall = sth + thN;
   const double freeboard = GS(FREEBOARD), psi_g_snow = GS(PSI_G_SNOW);
   double flood_brine = -g.dt * grav_f * rho_l * rho_l * hp * (freeboard) / (mu * sall);
   const double shift_ice = flood_brine / (rho_l * psi_g_snow / ratio_flood);
   const double shift_snow = shift_ice * (1 + psi_g_snow / (1.0 - psi_g_snow) * (1.0 - 1.0 / ratio_flood));
-
-  double S1 = LAY(SAMSIM_A_S_ABS, 1), H1 = LAY(SAMSIM_A_H_ABS, 1), m1 = LAY(SAMSIM_A_M, 1), th1 = LAY(SAMSIM_A_THICK, 1);
-  double SN = LAY(SAMSIM_A_S_ABS, Na), HN = LAY(SAMSIM_A_H_ABS, Na);
-  const double mN = LAY(SAMSIM_A_M, Na), TN = LAY(SAMSIM_A_T, Na);
+  double S1 = e.S1, H1 = e.H1, m1 = e.m1, th1 = e.th1;
+  const double SN = e.SN, HN = e.HN, mN = e.mN, TN = e.TN;
   const double S_buN = SN / mN;
 
   S1 = S1 + flood_brine * S_buN;
@@ -1254,11 +1285,13 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
   CL(m_snow) = CL(m_snow) - shift_snow / CL(thick_snow) * CL(m_snow);
   CL(thick_snow) = CL(thick_snow) - shift_snow;
 
-  if (freeboard + shift_ice < neg_free) {
+  e.deep = freeboard + shift_ice < neg_free;
+  e.incS = 0.0; e.incH = 0.0;
+  if (e.deep) {
     const double shift = neg_free - (freeboard + shift_ice);
     flood_brine = shift * (psi_g_snow) * rho_l;
-    SN = SN + (x.S_bu_bottom - S_buN) * flood_brine;
-    HN = HN + (g.T_bottom - TN) * c_l * flood_brine;
+    e.incS = (x.S_bu_bottom - S_buN) * flood_brine;
+    e.incH = (g.T_bottom - TN) * c_l * flood_brine;
     S1 = S1 + S_buN * flood_brine;
     H1 = H1 + TN * c_l * flood_brine;
     m1 = m1 + flood_brine;
@@ -1268,14 +1301,48 @@ __device__ RARE void flood(Col &c, const Ctx &x) {
     m1 = m1 + shift / CL(thick_snow) * CL(m_snow);
     CL(m_snow) = CL(m_snow) - shift / CL(thick_snow) * CL(m_snow);
     CL(thick_snow) = CL(thick_snow) - shift;
-    LAY(SAMSIM_A_S_ABS, Na) = SN;
-    LAY(SAMSIM_A_H_ABS, Na) = HN;
   }
-  LAY(SAMSIM_A_S_ABS, 1) = S1;
-  LAY(SAMSIM_A_H_ABS, 1) = H1;
-  LAY(SAMSIM_A_M, 1) = m1;
-  LAY(SAMSIM_A_THICK, 1) = th1;
-  c.bgc_flood = flood_brine;
+  e.S1 = S1; e.H1 = H1; e.m1 = m1; e.th1 = th1;
+  return flood_brine;
+}
+
+template <class K>
+__device__ RARE void flood(Col &c, const Ctx &x) {
+  const samsim_config &g = x.p->cfg;
+  const int Na = c.Na;
+  // harmonic-mean permeability of the column and its total thickness: from the first sweep of this step (flood_handover); without
+  // Rayleigh-number drainage (grav_flag 1: no scan) the column is walked here
+  double hp, sall;
+  if (CFG(grav_flag) >= 2) {
+    hp = SPEC(SP_FL_HP);
+    sall = SPEC(SP_FL_SALL);
+  } else {
+    double sth = 0.0;
+    hp = 0.0;
+    for (int k = 1; k <= Na - 1; ++k) {
+      const double thick = LAY(SAMSIM_A_THICK, k);
+      const double perm = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, k));
+      hp = hp + thick / perm;
+      sth += thick;
+    }
+    const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
+    const double permN = x.p17 * pow_3p1(1000.0 * LAY(SAMSIM_A_PSI_L, Na));
+    hp = hp + (thN * psN / psi_s_min) / permN;
+    hp = (sth + thN * psN / psi_s_min) / hp;
+    sall = sth + thN;
+  }
+  FloodEnds e;
+  e.S1 = LAY(SAMSIM_A_S_ABS, 1); e.H1 = LAY(SAMSIM_A_H_ABS, 1); e.m1 = LAY(SAMSIM_A_M, 1); e.th1 = LAY(SAMSIM_A_THICK, 1);
+  e.SN = LAY(SAMSIM_A_S_ABS, Na); e.HN = LAY(SAMSIM_A_H_ABS, Na); e.mN = LAY(SAMSIM_A_M, Na); e.TN = LAY(SAMSIM_A_T, Na);
+  c.bgc_flood = flood_core<K>(c, x, hp, sall, e);
+  if (e.deep) {
+    LAY(SAMSIM_A_S_ABS, Na) = e.SN + e.incS;
+    LAY(SAMSIM_A_H_ABS, Na) = e.HN + e.incH;
+  }
+  LAY(SAMSIM_A_S_ABS, 1) = e.S1;
+  LAY(SAMSIM_A_H_ABS, 1) = e.H1;
+  LAY(SAMSIM_A_M, 1) = e.m1;
+  LAY(SAMSIM_A_THICK, 1) = e.th1;
 }
 
 // ---------------------------------------------------------------- flood_simple, mo_flood.f90:167-210 (flood_flag 3)
@@ -1301,26 +1368,22 @@ __device__ RARE void flood_simple(Col &c, const Ctx &x) {
 }
 
 // recompute ray(1) after flood changed thick(1) (thick(1) enters only the k = 1 harmonic mean)
+// (thick: the flooded thick(1); psi_l, S_br: the top layer's liquid fraction and brine salinity of this step's first sweep)
 template <class K>
-__device__ RARE void refresh_ray_top(Col &c, const Ctx &x) {
+__device__ RARE void refresh_ray_top(Col &c, const Ctx &x, double thick, double psi_l, double S_br) {
   const samsim_config &g = x.p->cfg;
-  const int Na = c.Na;
   if (CFG(harmonic_flag) != 2) return;  // MINVAL variant does not depend on thick(1)
-  double minp = 1.0e300, stp = 0.0, st = 0.0, height = 0.0;
-  const double thN = LAY(SAMSIM_A_THICK, Na), psN = LAY(SAMSIM_A_PSI_S, Na);
-  const double bot = thN * psN / psi_s_min;
-  const double botterm = bot / (x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, Na))));
-  for (int k = Na - 1; k >= 1; --k) {
-    const double thick = LAY(SAMSIM_A_THICK, k);
-    const double perm = x.p17 * pow_3p1(1000.0 * fabs(LAY(SAMSIM_A_PSI_L, k)));
-    height = st + bot;
-    minp = dmin(minp, perm);
-    stp = stp + thick / perm;
-    st = st + thick;
-  }
-  double hp = (minp < x.p14) ? 0.0 : (st + bot) / (stp + botterm);
-  double ray = grav_f * rho_l * bbeta * (LAY(SAMSIM_A_S_BR, 1) - LAY(SAMSIM_A_S_BR, Na)) * height * hp;
-  ray = ray / (kappa_l * mu);
+  // the scan over layers N_active..2 as the first sweep left it (flood_handover), completed with the flooded top layer exactly as
+  // s1_layer completes it
+  const double perm = x.p17 * pow_3p1(1000.0 * fabs(psi_l));
+  const double st2 = SPEC(SP_ST), bot = SPEC(SP_BOT);
+  const double height = st2 + bot;
+  const double minp = dmin(SPEC(SP_MINP), perm);
+  const double stp = SPEC(SP_STP) + quot(thick, perm);
+  const double st = st2 + thick;
+  const double hp = (minp < x.p14) ? 0.0 : quot(st + bot, stp + SPEC(SP_BOTTERM));
+  double ray = grav_f * rho_l * bbeta * (S_br - SPEC(SP_SBR_BOT)) * height * hp;
+  ray = ray * (1.0 / (kappa_l * mu));
   LAY(SAMSIM_A_RAY, 1) = dmax(ray, 0.0);
 }
 
@@ -1556,6 +1619,9 @@ template <class K>
 // couple: this column has a thin snow cover (snow_coupling, mo_grotz.f90:418-420, between the brine expulsion and the drainage);
 // late_rad: some column of the wave has, so the radiation header and the Beer-law pass -- which read the snow temperature the
 // coupling sets -- run inside the sweep, after the top two layers (time, tc, do_beer are theirs)
+// COLF_FLOODED: this column was flooded before the sweep (column_step, from a dry run of the expulsion): layer 1 takes the flooded
+// salt, enthalpy, mass and thickness (hand-over block) where the unfused order's flood() would have changed the arrays -- after its
+// expulsion and mass_transfer, before its drainage -- and the bottom layer the increments of an instant flooding (COLF_FLOOD_DEEP)
 __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool store_default, bool decide_psi, bool &surface_done,
                                                  bool couple, bool late_rad, double time, int tc, bool do_beer) {
   const samsim_config &g = x.p->cfg;
@@ -1655,8 +1721,11 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       LAYU(SAMSIM_A_PSI_G, j) = psi_g;
     }
     // sub_fl_Q (mo_thermo_functions.f90:201-223): fl_Q(j) = (T(j) - T(j-1)) / (thick(j-1)/(2k(j-1)) + thick(j)/(2k(j))) with the
-    // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op)
-    const double hr = quot(thick, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
+    // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op);
+    // th_l: the thickness the conduction and the drainage see (flooding changes layer 1's after the expulsion)
+    const bool flooded_here = FIRST && (c.flags & COLF_FLOODED) != 0;
+    const double th_l = flooded_here ? LAYU(SAMSIM_A_THICK, 1) : thick;
+    const double hr = quot(th_l, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
     const double flq = (j >= 2) ? quot(T - prev.T, hr_up + hr) : 0.0;
     if (j == 2) c.flq2 = flq;
     m = m + flm_next - flm_j;
@@ -1692,12 +1761,22 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       LAYU(SAMSIM_A_PHI, 1) = phi1;
       if (rcc && !c.status) { c.status = rcc; x.err_step[c.col] = c.step + 1; x.err_layer[c.col] = 1; }
     }
+    if (flooded_here) {   // flooding (mo_grotz.f90:428-445) sits here in the reference's order: flood() on the finished expulsion
+      S_abs = SPEC(SP_FLD_S1); H_abs = SPEC(SP_FLD_H1); m = SPEC(SP_FLD_M1);
+      ch = true;
+      c.flags &= ~COLF_FLOODED;
+    }
     if (LAST) {
       if (psi_g > 0.0) {  // bottom-layer gas -> ocean water
         const double t2 = psi_g * thick * rho_l;
         m = m + t2;
         S_abs = S_abs + t2 * x.S_bu_bottom;
         H_abs = H_abs + t2 * c_l * g.T_bottom;
+      }
+      if (c.flags & COLF_FLOOD_DEEP) {   // instant flooding below neg_free: ocean water into the bottom layer (mo_flood.f90:118-121)
+        S_abs = S_abs + SPEC(SP_FL_HP);
+        H_abs = H_abs + SPEC(SP_FL_SALL);
+        c.flags &= ~COLF_FLOOD_DEEP;
       }
       if (CFG(turb_flag) == 2) {  // sub_turb_flux
         const double turb = Turb_A * exp(Turb_B * (-ocean_density<K>(x) + func_density(T, S_abs / m))) * dt;
@@ -1714,19 +1793,19 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       // S_br(j+1) of the first sweep, from the request buffer of layer j+1 (same operands and operations as finish())
       if (ray > ray_crit && S_br > S_br_below(below)) {
         const double psi_s = ex.psi_s;
-        if (psi_s > 0.001 && quot(SA, mA) > 0.1) {  // S_bu of this layer (j < N_active: nothing changed since A)
+        if (psi_s > 0.001 && (flooded_here ? quot(S_abs, m) : quot(SA, mA)) > 0.1) {  // S_bu of this layer (j < N_active: nothing but a flooding changed it since A)
           ST_COUNT(CT_DRAIN_WAVE, 1);
           ST_COUNT(CT_DRAIN_LANE, (unsigned long long)__popcll(__ballot(1)));
           const double psi_l = ex.psi_l;
-          double flux = x_grav * (ray - ray_crit) * dt * thick;
-          flux = dmin(flux, psi_l * rho_l * thick);
+          double flux = x_grav * (ray - ray_crit) * dt * th_l;
+          flux = dmin(flux, psi_l * rho_l * th_l);
           S_abs = S_abs - flux * S_br;
           if (S_abs < 0.0 && !stop_layer) stop_layer = j;
           CL(grav_temp) = CL(grav_temp) + flux * Tl;
           H_abs = H_abs - flux * c_l * Tl;
           heat_loss = heat_loss + flux * c_l * Tl;
           cum = cum + flux;
-          flup = dmin(cum, psi_l * rho_l * thick);
+          flup = dmin(cum, psi_l * rho_l * th_l);
           ch = true;
         }
       }
@@ -1773,7 +1852,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   auto request = [&](const int j) { ahead2 = load_ld(j + 2 <= N ? j + 2 : N); };      // top of iteration j: layer j+2
   auto advance = [&](const int j) { raw = finish(ahead, j + 1); ahead = ahead2; };      // end of iteration j: layer j+1 becomes current
   // ---- layers 1 and 2 (where they are interior layers), volume fractions always stored
-  const double thick1 = LAYU(SAMSIM_A_THICK, 1);
+  const double thick1 = (c.flags & COLF_FLOODED) ? SPEC(SP_FLD_TH1_BEFORE) : LAYU(SAMSIM_A_THICK, 1);   // (the expulsion of layer 1 saw the unflooded thickness)
   if (1 < Na) { request(1); layer(1, ahead, thick1, recip(thick1), std::false_type{}, std::true_type{}); advance(1); }
   if (2 < Na) { request(2); layer(2, ahead, g.thick_0, recip(g.thick_0), std::false_type{}, std::false_type{}); advance(2); }   // (N_top >= 3: samsim_create)
   if (late_rad) {   // (see the head of the routine; nothing above reads fl_rad, the albedo or the short-wave flux)
@@ -2807,10 +2886,10 @@ __device__ RARE void down_unfused(Col &c, const Ctx &x, long long col, double ti
         GS(FREEBOARD) = (buoy - CL(m_snow)) / rho_l;
         if (GS(FREEBOARD) < 0.0 && CFG(flood_flag) == 2) {
           flood<K>(c, x);
-          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
+          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x, LAY(SAMSIM_A_THICK, 1), LAY(SAMSIM_A_PSI_L, 1), LAY(SAMSIM_A_S_BR, 1));
         } else if (K::general && CFG(flood_flag) == 3 && GS(FREEBOARD) < neg_free) {
           flood_simple<K>(c, x);
-          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x);
+          if (CFG(grav_flag) >= 2) refresh_ray_top<K>(c, x, LAY(SAMSIM_A_THICK, 1), LAY(SAMSIM_A_PSI_L, 1), LAY(SAMSIM_A_S_BR, 1));
         }
       }
     }
@@ -2931,7 +3010,8 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool flood_possible = (CFG(flood_flag) > 1 && CL(m_snow) > 0.0 && CFG(freeboard_snow_flag) == 0 &&
                                CL(m_snow) > c.buoy_s * (rho_l - rho_s));
   // (a thin snow cover no longer needs the unfused order: the fused down sweep couples it to the top layer in place)
-  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && !flood_possible &&
+  // (a possible flooding no longer needs it either where flood_flag is 2 and no thin snow is coupled in the same step: see below)
+  const bool fused_col = do_grav && !out_step && (c.step + 1 != 1) && (!flood_possible || (CFG(flood_flag) == 2 && !coupling)) &&
                      !(K::general && CFG(testcase) == 5 && c.step + 1 == 2) && !HAS_BGC &&
                      !(K::general && CFG(prescribe_flag) == 2)
                      && (c.flags & COLF_REGULAR) != 0   // the fused down sweep takes the thicknesses from the grid rule only
@@ -2959,6 +3039,42 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   bool surface_done = false;   // the fused down sweep has evaluated the surface balance already
   if (fused) {
     ST_COUNT(CT_FUSED, 1);
+    // Flooding (mo_grotz.f90:428-445) sits between the brine expulsion and the gravity drainage.  Whether a column floods is
+    // decided from the gas volume expulsion_flux leaves (freeboard) and what it moves depends on the top and bottom layers after the
+    // expulsion -- both known only once the expulsion has gone through the whole column, while the fused sweep drains layer 1 long
+    // before.  So a column whose snow load makes flooding possible first takes a DRY RUN of the expulsion (four loads per layer, no
+    // store), floods its top and bottom layers and snow in registers exactly as flood() does on the arrays, and hands the fused sweep
+    // the flooded top layer; the Rayleigh number of layer 1 is redone with the flooded thickness from the first sweep's scan.  One
+    // read-only pass instead of the unfused order's three extra sweeps (and flood / refresh_ray_top no longer walk the column at
+    // all): BASELINE cfg5, where every column floods in every step.
+    if (flood_possible) {
+      ExpelledEnds en;
+      sweep_expulsion_transfer<K, true>(c, x, &en);
+      THICK_RULE_INIT(tr);
+      if (en.psi_gN > 0.0) {   // bottom-layer gas -> ocean water (mo_grotz.f90:405-410) precedes the flooding block
+        const double temp2 = en.psi_gN * THICK_AT(tr, Na) * rho_l;
+        en.mN = en.mN + temp2;
+        en.SN = en.SN + temp2 * x.S_bu_bottom;
+        en.HN = en.HN + temp2 * c_l * g.T_bottom;
+      }
+      const double buoy = c.buoy_s * (rho_l - rho_s) + en.buoy_g * rho_l;
+      if (CL(m_snow) > buoy) {
+        GS(FREEBOARD) = (buoy - CL(m_snow)) / rho_l;
+        if (GS(FREEBOARD) < 0.0) {
+          FloodEnds e;
+          e.S1 = en.S1; e.H1 = en.H1; e.m1 = en.m1; e.th1 = LAY(SAMSIM_A_THICK, 1);
+          e.SN = en.SN; e.HN = en.HN; e.mN = en.mN; e.TN = en.TN;
+          const double th1_before = e.th1;
+          flood_core<K>(c, x, SPEC(SP_FL_HP), SPEC(SP_FL_SALL), e);
+          LAY(SAMSIM_A_THICK, 1) = e.th1;
+          refresh_ray_top<K>(c, x, e.th1, en.psi_l1, en.S_br1);
+          // (the scan rows have served: they carry the flooded top layer to the down sweep, see samsim_device.h)
+          c.flags |= COLF_FLOODED;
+          SPEC(SP_FLD_S1) = e.S1; SPEC(SP_FLD_H1) = e.H1; SPEC(SP_FLD_M1) = e.m1; SPEC(SP_FLD_TH1_BEFORE) = th1_before;
+          if (e.deep) { c.flags |= COLF_FLOOD_DEEP; SPEC(SP_FL_HP) = e.incS; SPEC(SP_FL_SALL) = e.incH; }
+        }
+      }
+    }
     // testcase specifics (mo_grotz.f90:503-565) and the radiation header only read time, snow scalars and psi_l(1),
     // none of which the down sweep changes, so they can run first
     testcase_scalars<K>(c, x, g, time);

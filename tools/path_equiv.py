@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--ncol", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--fixture", default="sheba_ensemble_80_day345.npz")
+    ap.add_argument("--cfg5", action="store_true", help="the Nlayer-500 flooding slab of BASELINE cfg5 (every column floods in every step)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2, default=None)
     a = ap.parse_args()
@@ -53,8 +54,13 @@ def main():
         sys.exit(0 if ok else 1)
     import samsim_amd
     from samsim_amd import testcases as tcs
-    z, st, clock, _ = bench.load_ensemble(a.fixture)
-    cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
+    if a.cfg5:
+        from samsim_amd.capi import State
+        cfg, st, clock = tcs.config5(1, nlayer=500)
+        st = State(np.ascontiguousarray(st.lay[:4]), st.scal, st.n_active)
+    else:
+        z, st, clock, _ = bench.load_ensemble(a.fixture)
+        cfg, _ = tcs.testcase4(1, nlayer=int(z["nlayer"]), n_top=int(z["n_top"]), n_bottom=int(z["n_bottom"]))
     g = samsim_amd.hip_solver(cfg, a.ncol)
     dT, ps = tcs.ensemble_perturbation(a.ncol)
     g.set_forcing(*bench.sheba_forcing(), dT, ps)

@@ -41,7 +41,8 @@ def main():
                     continue
                 per_dispatch.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
                 per_dispatch[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-                out.setdefault("vgpr", int(r["VGPR_Count"]))
+                # (rocprofv3's VGPR_Count column is not the compiler's register count -- 64 where the kernel is built for 128 --
+                # so it is left out: profiles/r*_resource_usage.txt holds the compiler's remarks)
                 out.setdefault("lds_block_bytes", int(r["LDS_Block_Size"]))
                 out.setdefault("scratch_bytes_per_lane", int(r["Scratch_Size"]))
             for n, d in per_dispatch.items():
