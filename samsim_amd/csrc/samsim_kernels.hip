@@ -253,10 +253,7 @@ struct Col {
 #ifndef SAMSIM_PATH_MODE
 #define SAMSIM_PATH_MODE 2
 #endif
-// experiment: the fused up sweep requests its operands 3 layers ahead instead of 2
-#ifndef SAMSIM_UAHEAD
-#define SAMSIM_UAHEAD 2
-#endif
+
 static_assert(SAMSIM_BLOCK == 64, "the blocked layer layout, launch() and DEV_LAY_INDEX are written for one 64-lane wave per column block");
 // Address of element (a, k): one 32-bit offset register per row serves all arrays of the row (a 64-bit per-lane address for every
 // array costs two registers each and 64-bit vector arithmetic per access).
@@ -2179,10 +2176,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   auto load4 = [&](int j) -> UL { UL u = load3(j); u.th = LAYU(SAMSIM_A_THICK, j); return u; };
   if (regular_wave) {
     cur = load3(Na); nxt = load3(Na >= 2 ? Na - 1 : 1); nn = nxt;   // layers k, k-1, k-2
-#if SAMSIM_UAHEAD == 3
-    nn = load3(Na >= 3 ? Na - 2 : 1);
-    UL n3 = nn;                                                      // layer k-3
-#endif
+
     const int b0 = g.n_top, b1 = g.n_top + g.n_middle;
     int k = kmax;
     for (int stretch = 0; stretch < 3; ++stretch) {
@@ -2193,15 +2187,9 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         ISA_MARK("U_ITER_BEGIN");
         ST_MARK(ST_UP);
         if (k > Na) continue;
-#if SAMSIM_UAHEAD == 3
-        n3 = load3(k >= 4 ? k - 3 : 1);
-        body(k, th_s, rth_s, std::false_type{});
-        cur = nxt; nxt = nn; nn = n3;
-#else
-        nn = load3(k >= 3 ? k - 2 : 1);
+        nn = load3(k >= 3 ? k - 2 : 1);    // (three layers ahead: no faster, gpurun_out/r3f)
         body(k, th_s, rth_s, std::false_type{});
         cur = nxt; nxt = nn;
-#endif
         ISA_MARK("U_ITER_END");
       }
     }
@@ -3020,13 +3008,11 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // with part of its lanes idle -- the normal state of a melt season, when some column of almost every wave has thin snow or a
   // flooded surface.  The unfused path is the general one (the reference's order, literally) and gives a column the same bits as
   // the fused one (tools/path_equiv.py compares the two on the GPU), so a wave in which any column needs it takes it for all.
-  // 0 = per column, 1 = always unfused (the checker's reference for path_equiv).
+  // SAMSIM_PATH_MODE 1 = always unfused (the build tools/path_equiv.py compares the product with).
 #if SAMSIM_PATH_MODE == 1
   const bool fused = false;
-#elif SAMSIM_PATH_MODE == 2
-  const bool fused = (__ballot(!fused_col) == 0ull);
 #else
-  const bool fused = fused_col;
+  const bool fused = (__ballot(!fused_col) == 0ull);
 #endif
 
   ST_MARK(ST_PRO);

@@ -18,7 +18,12 @@ pairs = [("bench_default.json", f"{rnd}_bench.json"), ("pmc_summary_500.json", f
          ("stamps_winter.json", f"{rnd}_stamps_winter.json"), ("stamps_melt.json", f"{rnd}_stamps_melt.json"),
          ("counters_winter.json", f"{rnd}_counters_winter.json"), ("counters_melt.json", f"{rnd}_counters_melt.json"),
          ("bench_tc1.json", f"{rnd}_bench_tc1.json"), ("bench_cfg5.json", f"{rnd}_bench_cfg5.json"),
-         ("bench_nlayer100.json", f"{rnd}_bench_nlayer100.json")]
+         ("bench_nlayer100.json", f"{rnd}_bench_nlayer100.json"), ("bench_two_ranks_one_gpu.json", f"{rnd}_bench_two_ranks_one_gpu.json"),
+         ("path_equiv_cfg5.json", f"{rnd}_path_equiv_cfg5.json"),
+         ("path_equiv_sheba_ensemble_80.npz.json", f"{rnd}_path_equiv_sheba_ensemble_80.json"),
+         ("path_equiv_sheba_ensemble_80_day345.npz.json", f"{rnd}_path_equiv_sheba_ensemble_80_day345.json"),
+         ("div_probe.txt", f"{rnd}_div_probe.txt"), ("layout_probe.txt", f"{rnd}_layout_probe.txt"),
+         ("bench_steps20.json", f"{rnd}_bench_steps20.json"), ("melt_ensemble_status.json", f"{rnd}_melt_ensemble_status.json")]
 for a, b in pairs:
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(P, b))

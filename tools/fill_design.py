@@ -5,7 +5,7 @@ import json
 import re
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
 P = "profiles/%s_" % rnd
 b = json.load(open(P + "bench.json"))
 pm = json.load(open(P + "pmc_summary_substeps500.json"))
@@ -16,16 +16,21 @@ ms = b["roofline"]["mean_launch_ms"]
 v = {
     "MS": "%.0f" % ms, "CTS": "%.2e" % b["value"], "FRAC": "%.3f" % b["roofline"]["frac"],
     "BPC": "%.0f" % pm["hbm_bytes_per_layer_cell"], "RATIO": "%.2f" % pm["traffic_over_algorithmic"],
-    "VALU": "%.0f" % ins["SQ_INSTS_VALU"], "SALU": "%.0f" % ins["SQ_INSTS_SALU"], "SCR": "%d" % pm["scratch_bytes_per_lane"],
+    "VALU": "%.0f" % ins["SQ_INSTS_VALU"], "SALU": "%.0f" % ins["SQ_INSTS_SALU"], "BRANCH": "%.0f" % ins["SQ_INSTS_BRANCH"],
+    "SCR": "%d" % pm["scratch_bytes_per_lane"],
     "MELT": "%.2e" % b["extra"]["stages"]["day360"]["column_timesteps_per_s"],
+    "M345": "%.2e" % b["extra"]["stages"]["day345"]["column_timesteps_per_s"],
+    "TRACEMS": "%.0f" % pm["kernel_trace"]["first_start_to_last_end_per_step_ms"],
     "F300": "%.2e" % b["extra"]["first_300_days"]["column_timesteps_per_s"],
     "TC1": "%.3f" % tc1["roofline"]["frac"], "CFG5": "%.3f" % cfg5["roofline"]["frac"],
     "VBUSY": "%.0f" % (100 * pm["valu_busy_frac"]),
     "TBS": "%.1f" % (pm["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12),
 }
-tmpl = open("DESIGN.md").read()
-for k, x in v.items():
-    tmpl = tmpl.replace("@%s@" % k, x)
-left = re.findall(r"@[A-Z0-9]+@", tmpl)
-open("DESIGN.md", "w").write(tmpl)
+left = []
+for doc in ("DESIGN.md", "README.md"):
+    tmpl = open(doc).read()
+    for k, x in v.items():
+        tmpl = tmpl.replace("@%s@" % k, x)
+    left += re.findall(r"@[A-Z0-9]+@", tmpl)
+    open(doc, "w").write(tmpl)
 print(v, "unfilled:", left)
