@@ -293,6 +293,9 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // first executing lane of the wave (divergent callers included)
+// does any active lane of the wave hold the predicate?  (the ballot of a comparison result IS its lane mask: one scalar compare,
+// where __ballot() first turns the predicate into an integer per lane and compares that again)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ bool wave_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
 
 #include "samsim_div.h"
@@ -488,24 +491,30 @@ __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, 
   const double A0 = -latent_heat - H, LS = latent_heat * S_bu;
   const NewtonConsts nc = newton_consts(s);
   double T;
-  bool more, ok;
-  newton_eval(s, nc, A0, LS, T_in, T, more, ok);
-  bool odd = !mushy || !ok;
-  more = more && !odd;
+  bool more0, ok;
+  newton_eval(s, nc, A0, LS, T_in, T, more0, ok);
+  // `more` and `odd` travel through the loop as 0 / 1 words in vector registers, not as lane masks: the loop test is then one compare
+  // whose result is the branch condition and the select mask of the update at once
+  int odd_i = (!mushy || !ok) ? 1 : 0;
+  int more_i = (more0 && odd_i == 0) ? 1 : 0;
   int i = 0;
   ISA_MARK("NEWTON_LOOP");
-  while (__ballot(more) != 0ull) {
+  for (;;) {
+    const bool more = more_i != 0;
+    if (__builtin_amdgcn_ballot_w64(more) == 0ull) break;
     double Tn;
     bool m2, ok2;
     newton_eval(s, nc, A0, LS, T, Tn, m2, ok2);
-    if (more && (T > 0.0 || T < -200.0 || !ok2)) odd = true;     // (the test is on the iterate the evaluation started from)
+    const bool left = (T > 0.0 || T < -200.0 || !ok2);   // (the test is on the iterate the evaluation started from)
 #if SAMSIM_STAMPS == 2
     if (evals && more) *evals += 1;
 #endif
     T = more ? Tn : T;
-    more = more && m2 && !odd;
-    if (++i == 260) { if (more) odd = true; break; }
+    odd_i = left ? (odd_i | more_i) : odd_i;
+    more_i = (left || !m2) ? 0 : more_i;
+    if (++i == 260) { odd_i |= more_i; break; }       // no convergence in 260 evaluations: the general routine reports it (STOP 99)
   }
+  const bool odd = odd_i != 0;
   ISA_MARK("NEWTON_LOOP_END");
   double phi = 1.0 - quot(S_bu, S_br_clamped(s, T, S_bu));
   int rc = 0;
@@ -544,10 +553,13 @@ namespace {
 // x*x*x * exp(0.1*log(x)) with a plain logarithm: within ~4 ulp of the correctly rounded power (samsim_pow.h)
 __device__ __forceinline__ double pow_3p1(double x) { return sp_pow_3p1(x); }
 
+__device__ __forceinline__ double pow_1p5(double x) { return sp_pow_1p5(x); }   // samsim_pow.h
+__device__ __forceinline__ double pow_4(double x) { return sp_pow_4(x); }
+
 // func_density, mo_functions.f90:51-62
 __device__ double func_density(double T, double S) {
   double density_0 = 999.842594 + 6.8 / 100.0 * T;
-  return density_0 + 0.825 * S + (-5.7 / 1000.0) * pow(dmax(S, 0.0), 1.5);
+  return density_0 + 0.825 * S + (-5.7 / 1000.0) * pow_1p5(dmax(S, 0.0));
 }
 
 // func_T_freeze, mo_functions.f90:239-250 (float32 products of default-REAL literals)
@@ -556,7 +568,7 @@ __device__ double func_T_freeze(double S_bu, int salt_flag, double tf_c3) {
     return -0.0592 * S_bu - (double)9.37f * (S_bu * S_bu) - tf_c3 * (S_bu * S_bu * S_bu);
   } else {
     const float a = 1.710523f * 1e-3f, b = 2.154996f * 1e-4f;
-    return -0.0575 * S_bu + (double)a * pow(S_bu, 1.5) - (double)b * (S_bu * S_bu);
+    return -0.0575 * S_bu + (double)a * pow_1p5(S_bu) - (double)b * (S_bu * S_bu);
   }
 }
 
@@ -567,7 +579,7 @@ __device__ double func_albedo(double thick_snow, double T_snow, double psi_l, do
   double albedo;
   if (thick_snow > thick_min) {
     albedo = (T_snow < (double)(-0.01f)) ? snow_dry : snow_wet;
-    albedo = ice_dry + (albedo - ice_dry) * dmin(1.0, thick_snow / 0.3);
+    albedo = ice_dry + (albedo - ice_dry) * dmin(1.0, quot(thick_snow, 0.3));
   } else {
     if (psi_l > 0.9) albedo = water;
     else if (psi_l > 0.6) albedo = ice_wet + (water - ice_wet) * ((psi_l - 0.6) / 0.3);
@@ -584,8 +596,8 @@ __device__ double func_albedo(double thick_snow, double T_snow, double psi_l, do
 // func_k_snow, mo_snow.f90:560-573
 __device__ double func_k_snow(double m_snow, double thick_snow) {
   const double c0 = 0.138, c1 = -1.01 / 1000.0, c2 = 3.233 / 1000000.0;
-  double r = m_snow / thick_snow;
-  double k_snow = c0 + c1 * m_snow / thick_snow + c2 * (r * r);
+  double r = quot(m_snow, thick_snow);
+  double k_snow = c0 + quot(c1 * m_snow, thick_snow) + c2 * (r * r);
   return k_snow + (double)0.15f;
 }
 
@@ -833,14 +845,14 @@ __device__ RARE void snow_block(Col &c, const Ctx &x) {
   double m = LAY(SAMSIM_A_M, 1), thick = LAY(SAMSIM_A_THICK, 1), H_abs = LAY(SAMSIM_A_H_ABS, 1);
   bool touched = false;
   double phi_snow = 0.0, max_lwc, max_lwc_v, sat_snow;
-  const double H_snow = CL(H_abs_snow) / CL(m_snow), S_bu_snow = S_abs_sn / CL(m_snow), psi_s_old = CL(psi_s_snow);
+  const double H_snow = quot(CL(H_abs_snow), CL(m_snow)), S_bu_snow = quot(S_abs_sn, CL(m_snow)), psi_s_old = CL(psi_s_snow);
   const double T_in = CL(T_snow);
   double T_sn = T_in;
   int rc = getT(x.salt, H_snow, S_bu_snow, T_in, T_sn, phi_snow);
   CL(T_snow) = T_sn;
   if (rc) STOPC(99, 0);
-  CL(psi_s_snow) = CL(m_snow) * phi_snow / rho_s / CL(thick_snow);
-  psi_l_sn = CL(m_snow) * (1.0 - phi_snow) / rho_l / CL(thick_snow);
+  CL(psi_s_snow) = quot(quot(CL(m_snow) * phi_snow, rho_s), CL(thick_snow));
+  psi_l_sn = quot(quot(CL(m_snow) * (1.0 - phi_snow), rho_l), CL(thick_snow));
   if (CL(psi_s_snow) + psi_l_sn > 1.0) {
     CL(thick_snow) = CL(m_snow) * (phi_snow / rho_s + (1.0 - phi_snow) / rho_l);
     CL(psi_s_snow) = CL(m_snow) * phi_snow / rho_s / CL(thick_snow);
@@ -848,7 +860,7 @@ __device__ RARE void snow_block(Col &c, const Ctx &x) {
     if (fabs(CL(psi_s_snow) + psi_l_sn - 1.0) > 0.0000001) { GS(PSI_L_SNOW) = psi_l_sn; STOPC(345, 0); }
   }
   psi_g_sn = 1.0 - CL(psi_s_snow) - psi_l_sn;
-  if (CL(psi_s_snow) > 0.0) max_lwc = 0.057 * (1.0 - CL(psi_s_snow)) / (CL(psi_s_snow)) + 0.017;
+  if (CL(psi_s_snow) > 0.0) max_lwc = quot(0.057 * (1.0 - CL(psi_s_snow)), CL(psi_s_snow)) + 0.017;
   else max_lwc = 0.0;
 
   if (psi_s_old > CL(psi_s_snow) && CL(psi_s_snow) > 0.0) {
@@ -989,7 +1001,7 @@ __device__ __forceinline__ void s1_layer(Col &c, const Ctx &x, int k, int Na, bo
       ray = dmax(ray, 0.0);
       if (!sparse_rows) {
         LAYU(SAMSIM_A_RAY, k) = ray;
-      } else if (k == 1 || x.ray_rows_all || __ballot(ray > ray_crit) != 0ull) {  // wave-uniform k, see Ctx::rflag (row 1 always: ray_row_valid)
+      } else if (k == 1 || x.ray_rows_all || wave_any(ray > ray_crit)) {  // wave-uniform k, see Ctx::rflag (row 1 always: ray_row_valid)
         LAYU(SAMSIM_A_RAY, k) = ray;
         // (every executing lane reads the word, sets the same bit and writes the same value back -- two LDS instructions in
         // lock-step, no leader to elect: the lane number a leader test compares with was one more value carried through the loop)
@@ -1043,7 +1055,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x, bool all_phi, 
   bool regular = true;
   const double th_mid_rule = LAYU(SAMSIM_A_THICK, g.n_top + 1);
   const bool check_col = (c.flags & COLF_REGULAR) == 0 || (c.flags & (COLF_RESTART | COLF_REGRID)) != 0;
-  const bool check_wave = __ballot(check_col) != 0ull;
+  const bool check_wave = wave_any(check_col);
   const int kmax = wave_max(Na);
   auto run = [&](auto check_tag) {
     constexpr bool CHECK = decltype(check_tag)::value;
@@ -1245,7 +1257,7 @@ __device__ RARE void vital_signs(Col &c, const Ctx &x) {
   c.freshwater = c.freshwater * (1.0 - sS / sm / ref_salinity);
   c.freshwater = c.freshwater + CL(m_snow) / rho_l;
   resist = resist + thN * psN / psi_s_min * (psi_s_min * k_s + 1.0 - psi_s_min * k_l);
-  if (CL(thick_snow) > g.thick_min / 110.0) resist = resist + CL(thick_snow) / func_k_snow(CL(m_snow), CL(thick_snow));
+  if (CL(thick_snow) > g.thick_min / 110.0) resist = resist + quot(CL(thick_snow), func_k_snow(CL(m_snow), CL(thick_snow)));
   c.total_resist = resist;
   c.thickness = ((Na > 1) ? sth : 0.0) + thN * psN / psi_s_min;
   if (Na > 1) {
@@ -1776,7 +1788,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
         c.flags &= ~COLF_FLOOD_DEEP;
       }
       if (CFG(turb_flag) == 2) {  // sub_turb_flux
-        const double turb = Turb_A * exp(Turb_B * (-ocean_density<K>(x) + func_density(T, S_abs / m))) * dt;
+        const double turb = Turb_A * exp(Turb_B * (-ocean_density<K>(x) + func_density(T, quot(S_abs, m)))) * dt;
         S_abs = S_abs - turb * (S_abs / m - x.S_bu_bottom);
       }
     }
@@ -1832,7 +1844,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
         prev.H_abs = prev.H_abs + c.frad * dt;
         esum += H_b - prev.H_abs;
       }
-      if (__ballot(prev.ch) != 0ull) {   // (wave-uniform: a row is stored for all its columns or for none)
+      if (wave_any(prev.ch)) {   // (wave-uniform: a row is stored for all its columns or for none)
         LAYU(SAMSIM_A_M, j - 1) = prev.m;
         LAYU(SAMSIM_A_S_ABS, j - 1) = prev.S_abs;
       }
@@ -1870,7 +1882,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
     surface_flux<K>(c, x);
     surface_done = true;
     const double thick_min = g.thick_min;
-    const double Tf = func_T_freeze(LAYU(SAMSIM_A_S_ABS, 1) / LAYU(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
+    const double Tf = func_T_freeze(quot(LAYU(SAMSIM_A_S_ABS, 1), LAYU(SAMSIM_A_M, 1)), CFG(salt_flag), x.tf_c3);   // as mo_grotz.f90:634 will
     bool snow_wet = false;
     if (CL(thick_snow) > 0.0) {
       // snow_thermo finds liquid water iff H_abs_snow / m_snow > -latent_heat (getT's fresh branch); the up sweep adds
@@ -1995,13 +2007,13 @@ __device__ __forceinline__ double radiative_T_top(const Col &c, double fl_rest, 
   const double pen = (CL(thick_snow) < thick_min) ? penetr : 0.0;
   T_old = T_old + zeroK;
   double temp1 = (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) + fl_rest;
-  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
-  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 + emi * 3.0 * sigma * pow_4(T_old);
+  temp1 = quot(temp1, emi * 4.0 * sigma * (T_old * T_old * T_old));
   temp1 = temp1 - zeroK;
   T_old = temp1 + zeroK;
   temp1 = (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) + fl_rest;
-  temp1 = temp1 + emi * 3.0 * sigma * pow(T_old, 4.0);
-  temp1 = temp1 / (emi * 4.0 * sigma * (T_old * T_old * T_old));
+  temp1 = temp1 + emi * 3.0 * sigma * pow_4(T_old);
+  temp1 = quot(temp1, emi * 4.0 * sigma * (T_old * T_old * T_old));
   temp1 = temp1 - zeroK;
   return temp1;
 }
@@ -2039,15 +2051,15 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
 
   double Tf;
   if (CL(thick_snow) >= thick_min / 100.0) Tf = 0.0;
-  else Tf = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+  else Tf = func_T_freeze(quot(LAY(SAMSIM_A_S_ABS, 1), LAY(SAMSIM_A_M, 1)), CFG(salt_flag), x.tf_c3);
 
   GS(T_FREEZE) = Tf;
 
   const double k_snow = (CL(thick_snow) >= thick_min / 100.0) ? func_k_snow(CL(m_snow), CL(thick_snow)) : 0.0;
   // sub_fl_Q_snow, mo_snow.f90:498-518
-  const double flq_snow_ice = (T1 - CL(T_snow)) / (CL(thick_snow) / (2.0 * k_snow) + thick1 / (2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
+  const double flq_snow_ice = quot(T1 - CL(T_snow), quot(CL(thick_snow), 2.0 * k_snow) + quot(thick1, 2.0 * (psi_s1 * k_s + psi_l1 * k_l)));
   if (CL(T_top) > Tf && Na > 1) {
-    temp1 = emi * sigma * pow(Tf + zeroK, 4.0) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
+    temp1 = emi * sigma * pow_4(Tf + zeroK) - (1.0 - CL(albedo)) * (1.0 - pen) * CL(fl_sw) - fl_rest;
     if (CL(thick_snow) >= thick_min) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = flq_snow_ice; }
     else if (CL(thick_snow) >= thick_min / 100.0) { CL(fl_Q_snow) = temp1; CL(fl_Q1) = 0.0; }
     else CL(fl_Q1) = temp1;
@@ -2055,7 +2067,7 @@ __device__ __forceinline__ void surface_flux(Col &c, const Ctx &x) {
   } else {
     if (CL(thick_snow) >= thick_min) {
       CL(fl_Q1) = flq_snow_ice;
-      CL(fl_Q_snow) = (CL(T_snow) - CL(T_top)) / (CL(thick_snow) / (2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
+      CL(fl_Q_snow) = quot(CL(T_snow) - CL(T_top), quot(CL(thick_snow), 2.0 * k_snow));  // sub_fl_Q_0_snow, mo_snow.f90:528-546
     } else if (CL(thick_snow) > thick_min / 100.0 && CL(thick_snow) < thick_min) {
       CL(fl_Q1) = 0.0;
       // sub_fl_Q_0_snow_thin, mo_snow.f90:466-487
@@ -2108,7 +2120,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // block -- inside each of which thick and 1/thick are the same for every layer: the loop body neither loads nor selects them.  A
   // wave with a hand-made column loads the array with the other operands and forms 1/thick per layer.
   struct UL { double th, H, m, S; };
-  const bool regular_wave = __ballot((c.flags & COLF_REGULAR) == 0) == 0ull;
+  const bool regular_wave = !wave_any((c.flags & COLF_REGULAR) == 0);
   UL cur, nxt, nn;
   bool alive = true, neg_salt = false;
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
@@ -2983,7 +2995,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   // column changed below layer 1 since the last up sweep
   c.ray_all = (c.flags & COLF_DIRTY) != 0;
   // (sparse Rayleigh rows need wave-uniform layer indices and every column of the wave in the sweep)
-  const bool whole_wave = __ballot(!c.ray_all) == 0ull;
+  const bool whole_wave = !wave_any(!c.ray_all);
   if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); ST_COUNT(CT_L_DIRTY, (unsigned long long)__popcll(__ballot(1))); sweep_thermo_expulsion<K>(c, x, out_step, whole_wave); }
   else prologue_top_layer<K>(c, x);
   c.flags &= COLF_REGULAR;
@@ -3012,7 +3024,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
 #if SAMSIM_PATH_MODE == 1
   const bool fused = false;
 #else
-  const bool fused = (__ballot(!fused_col) == 0ull);
+  const bool fused = !wave_any(!fused_col);
 #endif
 
   ST_MARK(ST_PRO);
@@ -3065,7 +3077,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // none of which the down sweep changes, so they can run first
     testcase_scalars<K>(c, x, g, time);
     // with a thin snow cover somewhere in the wave the radiation header waits for the coupling inside the sweep (it reads T_snow)
-    const bool late_rad = __ballot(coupling) != 0ull;
+    const bool late_rad = wave_any(coupling);
     double beer0 = 0.0;
     if (!late_rad) {
       beer0 = radiation_header<K>(c, x, time, tc);
@@ -3124,7 +3136,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
     // boundflux_flag 3 (:649-663) runs the same block on the air temperature instead of the surface temperature
     const bool lab = K::general && CFG(boundflux_flag) == 3;
     const double T_surf = lab ? CL(T2m) : CL(T_top);
-    const double T_freeze = func_T_freeze(LAY(SAMSIM_A_S_ABS, 1) / LAY(SAMSIM_A_M, 1), CFG(salt_flag), x.tf_c3);
+    const double T_freeze = func_T_freeze(quot(LAY(SAMSIM_A_S_ABS, 1), LAY(SAMSIM_A_M, 1)), CFG(salt_flag), x.tf_c3);
     GS(T_FREEZE) = T_freeze;
     CL(melt_thick) = 0.0;
     const double psi_s1 = LAY(SAMSIM_A_PSI_S, 1);

@@ -121,4 +121,14 @@ SP_FN double sp_pow_3p1(double x) {
 #else
 SP_FN double sp_pow_3p1(double x) { return sp_pow_3p1_plain(x); }
 #endif
+// x**1.5 and x**4 of the per-step scalar code (freezing point mo_functions.f90:239-250, sea-water density :51-62, the two radiative
+// iterations mo_heat_fluxes.f90:115-148): the reference's compiler calls pow() for both.  x*sqrt(x) (the square root is correctly
+// rounded, on the host and on the GPU) and (x*x)*(x*x) are within 1.5 ulp of the exact power at a fifteenth of pow()'s instructions;
+// tests/test_host_logic.py measures them against powl with this header compiled for the host.
+#if defined(__HIPCC__)
+SP_FN double sp_pow_1p5(double x) { return x * __builtin_sqrt(x); }
+#else
+SP_FN double sp_pow_1p5(double x) { return x * sqrt(x); }
+#endif
+SP_FN double sp_pow_4(double x) { const double t = x * x; return t * t; }
 #endif
