@@ -64,6 +64,7 @@ enum dev_bgc_flux {
 #define COLF_RESTART 2  // first step after samsim_set_state: RAY holds the previous Rayleigh numbers
 #define COLF_FLOODED 32     // (within a step) the fused order flooded this column: the flooded top layer waits in the hand-over block
 #define COLF_FLOOD_DEEP 16  // (within a step) the fused order flooded this column below neg_free: the bottom layer's increments wait in the hand-over block
+#define COLF_FLUSHED 64  // flush3 ran in the previous step (a wave with such a column leaves the next step's first sweep to that step: sweep_up_fused LITE)
 #define COLF_REGRID 8   // layer_dynamics changed the grid in the previous step: the full first sweep checks the thickness rule again
 #define COLF_REGULAR 4  // the thicknesses of layers 2..N_active follow the grid rule (thick_0, and one common value in the middle
                         // block): the sweeps take them from two loaded values instead of the array (checked by the full first

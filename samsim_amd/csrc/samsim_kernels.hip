@@ -56,7 +56,7 @@ enum { ST_PRO = 0, ST_DFUSED, ST_DUNFUSED, ST_SURF, ST_UP, ST_POST, ST_HEAD, ST_
        CT_WAVESTEPS = 8, CT_FUSED, CT_UNFUSED, CT_UP_TRIPS, CT_NEWTON_WAVE, CT_NEWTON_LANE, CT_LANES, CT_DOWN_TRIPS, CT_DRAIN_WAVE,
        CT_DRAIN_LANE, CT_DIRTY, CT_L_COUPLING, ST_U_HEAD = 20, ST_U_GETT, ST_U_TAIL, ST_D_A, ST_D_B,
        CT_L_FLOODP = 25, CT_L_IRREG, CT_L_DIRTY, CT_L_UNFUSED, CT_L_FLUSH3, CT_L_REGRID, CT_L_FREEBOARD,
-       CT_REFILL = 32, CT_ROWS, CT_ROWS_STILL, ST_NSLOT = 48 };
+       CT_REFILL = 32, CT_ROWS, CT_ROWS_STILL, CT_ODD_LANES, CT_ODD_WAVES, CT_ODD_EVALS_WAVE, CT_LITE, ST_NSLOT = 48 };
 struct Stamps {
   unsigned long long *acc;   // [48] in LDS, one block = one wave
   unsigned long long t0;
@@ -432,6 +432,16 @@ __device__ __forceinline__ double T_liquid(double H) {
   return H * (1.0 / c_l);
 }
 
+// the temperature at which brine of salinity S_bu starts to freeze, mo_thermo_functions.f90:85-92 (Newton from -1 C)
+__device__ __forceinline__ double T_freeze_of(const Salt &s, double S_bu) {
+  double T_fr = -1.0;
+  while (fabs(S_br_poly(s, T_fr) / S_bu - 1.0) > (double)0.0001f) {  // tolerance is a float32 literal (:87)
+    const double t0 = T_fr;
+    T_fr = t0 - (S_br_poly(s, t0) - S_bu) / ddT_S_br(s, t0);
+  }
+  return T_fr;
+}
+
 // getT, mo_thermo_functions.f90:62-143: guarded Newton iteration for T and the solid mass fraction phi.
 // Returns 99 (the reference's STOP code) when 260 iterations do not converge.
 __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out, int *evals = nullptr) {
@@ -449,11 +459,7 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
         // The reference computes the freezing temperature T_fr up front (mo_thermo_functions.f90:85-92) and only reads it
         // here.  It has no other effect, so it is evaluated on first use: same value, no Newton loop in the common case.
         if (!have_T_fr) {
-          T_fr = -1.0;
-          while (fabs(S_br_poly(s, T_fr) / S_bu - 1.0) > (double)0.0001f) {  // tolerance is a float32 literal (:87)
-            const double t0 = T_fr;
-            T_fr = t0 - (S_br_poly(s, t0) - S_bu) / ddT_S_br(s, t0);
-          }
+          T_fr = T_freeze_of(s, S_bu);
           have_T_fr = true;
         }
         T_0 = T_fr;
@@ -485,6 +491,11 @@ __device__ __forceinline__ int getT(const Salt &s, double H, double S_bu, double
 // in winter, 7.1 against 4.4 in the melt season).  A lane that is anything else -- fresh ice, pure brine, an iterate that leaves
 // the interval and needs T_fr, S_br under 1e-4, no convergence -- is redone by the general routine above, on its own: what a lane
 // gets depends on its own column only, and the arithmetic (newton_eval) is the general routine's.
+// WARM (the sweeps of a melt season: the full first sweep, the up sweep of a flushing wave): an iterate that leaves (-200, 0) is
+// replaced by the freezing temperature inside the loop, exactly where the general routine does it, instead of sending the lane
+// through the general routine afterwards -- near 0 C a third of the layers of a wave hold such a lane, and each cost the wave a
+// second, slower iteration from the start.  The winter sweeps keep the loop without it (three registers less in their layer loop).
+template <bool WARM = false>
 __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, double T_in, double &T_out, double &phi_out, int *evals = nullptr) {
   const double Tl = T_liquid(H);
   const bool mushy = S_br_clamped(s, Tl, S_bu) > S_bu && S_bu > 0.001;
@@ -498,14 +509,25 @@ __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, 
   int odd_i = (!mushy || !ok) ? 1 : 0;
   int more_i = (more0 && odd_i == 0) ? 1 : 0;
   int i = 0;
+  double T_fr = 0.0;
+  bool have_T_fr = false;
   ISA_MARK("NEWTON_LOOP");
   for (;;) {
     const bool more = more_i != 0;
     if (__builtin_amdgcn_ballot_w64(more) == 0ull) break;
+    if (WARM) {
+      const bool out = more && (T > 0.0 || T < -200.0);
+      if (wave_any(out)) {
+        if (out) {
+          if (!have_T_fr) { T_fr = T_freeze_of(s, S_bu); have_T_fr = true; }
+          T = T_fr;
+        }
+      }
+    }
     double Tn;
     bool m2, ok2;
     newton_eval(s, nc, A0, LS, T, Tn, m2, ok2);
-    const bool left = (T > 0.0 || T < -200.0 || !ok2);   // (the test is on the iterate the evaluation started from)
+    const bool left = WARM ? !ok2 : (T > 0.0 || T < -200.0 || !ok2);   // (the test is on the iterate the evaluation started from)
 #if SAMSIM_STAMPS == 2
     if (evals && more) *evals += 1;
 #endif
@@ -520,7 +542,13 @@ __device__ __forceinline__ int getT_chain(const Salt &s, double H, double S_bu, 
   int rc = 0;
   if (odd) {
     phi = phi_out;
+#if SAMSIM_STAMPS == 2
+    int ev0 = evals ? *evals : 0;
+#endif
     rc = getT(s, H, S_bu, T_in, T, phi, evals);
+#if SAMSIM_STAMPS == 2
+    if (evals) *evals += ((*evals - ev0) << 16) | (1 << 30);   // (decoded by the caller: redone by the general routine, its evaluations)
+#endif
   }
   T_out = T;
   phi_out = phi;
@@ -1080,7 +1108,7 @@ __device__ RARE void sweep_thermo_expulsion(Col &c, const Ctx &x, bool all_phi, 
       double S_bu, H;
       per_mass(S_abs, H_abs, m, S_bu, H);
       double T, phi = 0.0;
-      int rr = getT_chain(s, H, S_bu, T_test, T, phi);
+      int rr = getT_chain<true>(s, H, S_bu, T_test, T, phi);
       if (rr && !rc) { rc = rr; rc_layer = k; }
       T_test = T;
       // T and phi are the hand-over to the down sweep; S_bu / S_br are recomputed there from T, S_abs, m
@@ -1120,7 +1148,7 @@ __device__ __forceinline__ void prologue_top_layer(Col &c, const Ctx &x) {
   if (K::general && CFG(prescribe_flag) == 2) LAY(SAMSIM_A_S_BU, 1) = S_abs / m;  // read back by prescribe_salinity
   const double T_test = (Na > 1) ? LAY(SAMSIM_A_T, 2) : g.T_bottom;
   double T, phi = 0.0;
-  const int rc = getT(x.salt, H, S_bu, T_test, T, phi);
+  const int rc = getT_chain(x.salt, H, S_bu, T_test, T, phi);   // (the wave's columns together, as in the sweeps)
   LAY(SAMSIM_A_T, 1) = T;
   LAY(SAMSIM_A_PHI, 1) = phi;
   s1_layer<K>(c, x, 1, Na, do_ray, T, phi, S_bu, m, thick, recip(thick), r);
@@ -2126,8 +2154,14 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   // One layer of the sweep.  TOP = layer 1, which alone meets the snow (mo_heat_fluxes.f90:291-303) and takes fl_Q(1) from the
   // surface balance: it runs after the loop, so that the loop body -- the same for every other layer -- carries neither the
   // thin-snow coupling (up to 200 getT pairs) nor its registers.
-  auto body = [&](const int k, const double th_k, const double rth_k, auto top_tag) {
+  // LITE: a wave with a column that flushed in the previous step will flush again in this one, after this sweep: flush3 rewrites
+  // every layer of that column, so the wave runs the full first sweep in the next step whatever this sweep prepares (the sweep costs
+  // a wave the same for one column as for 64) -- it then only runs the second getT chain, and says so for all its columns
+  // (COLF_DIRTY: the full first sweep gives a column the same bits as the fused one).  A wave that does not flush after all has lost
+  // nothing but the fused first sweep of one step.
+  auto body = [&](const int k, const double th_k, const double rth_k, auto top_tag, auto lite_tag) {
     constexpr bool TOP = decltype(top_tag)::value;
+    constexpr bool LITE = decltype(lite_tag)::value;
     const double H_k = cur.H, m_k = cur.m, S_k = cur.S;
     double H_abs = H_k;
     const double m = m_k;
@@ -2158,13 +2192,20 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     ST_MARK(ST_U_HEAD);
 #if SAMSIM_STAMPS == 2
     int evals = 1;
-    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi, &evals) : getT_chain(s, H, S_bu, T_test, T, phi, &evals);
+    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi, &evals) : getT_chain<LITE>(s, H, S_bu, T_test, T, phi, &evals);
+    {
+      const bool was_odd = (evals >> 30) & 1;
+      const int redo = (evals >> 16) & 0x3fff;
+      evals &= 0xffff;
+      const unsigned long long om = __ballot(was_odd);
+      if (om) { ST_COUNT(CT_ODD_LANES, (unsigned long long)__popcll(om)); ST_COUNT(CT_ODD_WAVES, 1); ST_COUNT(CT_ODD_EVALS_WAVE, (unsigned long long)wave_max(redo)); }
+    }
     ST_COUNT(CT_UP_TRIPS, 1);
     ST_COUNT(CT_NEWTON_WAVE, (unsigned long long)wave_max(evals));
     { int tot = 0; unsigned long long mk = __ballot(1); while (mk) { const int ln = __ffsll((long long)mk) - 1; tot += __builtin_amdgcn_readlane(evals, ln); mk &= mk - 1; }
       ST_COUNT(CT_NEWTON_LANE, (unsigned long long)tot); }
 #else
-    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi) : getT_chain(s, H, S_bu, T_test, T, phi);
+    int rr = TOP ? getT(s, H, S_bu, T_test, T, phi) : getT_chain<LITE>(s, H, S_bu, T_test, T, phi);
 #endif
     if (!TOP) { ISA_MARK("U_GETT_END"); }
     ST_MARK(ST_U_GETT);
@@ -2174,7 +2215,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     // the down sweeps recompute phi from T; the array is kept for its readers: the regrid trigger and layer_dynamics (bottom
     // two active layers), layer 1, the output snapshot and get_state
     if (store_phi || TOP || k >= Na - 1) LAYU(SAMSIM_A_PHI, k) = phi;
-    if (!TOP) {
+    if (!TOP && !LITE) {
       // first sweep of the next step for this layer (its own S_abs < 0 clamp first, mo_grotz.f90:812-818)
       // (a clamped salt mass changes S_bu and therefore T: such a column is left to the full sweep, flagged after the loop -- a
       // read-modify-write of the column's flag word inside the loop is one more value for the allocator to spill there)
@@ -2186,6 +2227,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
   const int kmax = wave_max(Na);
   auto load3 = [&](int j) -> UL { UL u; u.th = 0.0; u.H = LAYU(SAMSIM_A_H_ABS, j); u.m = LAYU(SAMSIM_A_M, j); u.S = LAYU(SAMSIM_A_S_ABS, j); return u; };
   auto load4 = [&](int j) -> UL { UL u = load3(j); u.th = LAYU(SAMSIM_A_THICK, j); return u; };
+  auto layers = [&](auto lite_tag) {
   if (regular_wave) {
     cur = load3(Na); nxt = load3(Na >= 2 ? Na - 1 : 1); nn = nxt;   // layers k, k-1, k-2
 
@@ -2200,7 +2242,7 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
         ST_MARK(ST_UP);
         if (k > Na) continue;
         nn = load3(k >= 3 ? k - 2 : 1);    // (three layers ahead: no faster, gpurun_out/r3f)
-        body(k, th_s, rth_s, std::false_type{});
+        body(k, th_s, rth_s, std::false_type{}, lite_tag);
         cur = nxt; nxt = nn;
         ISA_MARK("U_ITER_END");
       }
@@ -2210,18 +2252,23 @@ __device__ __forceinline__ void sweep_up_fused(Col &c, const Ctx &x, long long c
     for (int k = kmax; k >= 2; --k) {
       if (k > Na) continue;
       nn = load4(k >= 3 ? k - 2 : 1);
-      body(k, cur.th, recip(cur.th), std::false_type{});
+      body(k, cur.th, recip(cur.th), std::false_type{}, lite_tag);
       cur = nxt; nxt = nn;
     }
   }
+  };
+  const bool lite = K::fixed && CFG(flush_flag) == 5 && wave_any((c.flags & COLF_FLUSHED) != 0);
+  if (lite) { ST_COUNT(CT_LITE, 1); layers(std::true_type{}); } else layers(std::false_type{});
   __builtin_amdgcn_wave_barrier();   // the row flags are complete: the next readers are the down sweeps of the next step
-  if (neg_salt) c.flags |= COLF_DIRTY;
-  body(1, LAYU(SAMSIM_A_THICK, 1), 0.0, std::true_type{});
+  if (neg_salt || lite) c.flags |= COLF_DIRTY;
+  body(1, LAYU(SAMSIM_A_THICK, 1), 0.0, std::true_type{}, std::false_type{});
   if (!alive) return;
   // hand-over block for prologue_top_layer of the next step
+  if (!lite) {
   SPEC(SP_MINP) = r.minp; SPEC(SP_STP) = r.stp; SPEC(SP_ST) = r.st;
   SPEC(SP_BOT) = r.bot; SPEC(SP_BOTTERM) = r.botterm; SPEC(SP_PERM_BOT) = r.perm_bot;
   SPEC(SP_SBR_BOT) = r.S_br_bot; SPEC(SP_BUOY_S) = r.buoy_s; SPEC(SP_MIN_PSI_S) = r.min_psi_s;
+  }
   // energy conservation assert, mo_heat_fluxes.f90:265-310: (SUM(H_abs) + H_abs_snow) before + what went in - the same after,
   // with the two sums taken as one sum of per-layer differences
   double bal = esum + (H_abs_snow_before - CL(H_abs_snow));
@@ -2998,7 +3045,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   const bool whole_wave = !wave_any(!c.ray_all);
   if (c.ray_all) { ST_COUNT(CT_DIRTY, 1); ST_COUNT(CT_L_DIRTY, (unsigned long long)__popcll(__ballot(1))); sweep_thermo_expulsion<K>(c, x, out_step, whole_wave); }
   else prologue_top_layer<K>(c, x);
-  c.flags &= COLF_REGULAR;
+  c.flags &= (COLF_REGULAR | COLF_FLUSHED);
   if (c.status) return;
 
   int Na = c.Na;
@@ -3183,6 +3230,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
   }
 
   // flushing, mo_grotz.f90:670-737
+  c.flags &= ~COLF_FLUSHED;
   // freeboard (:670) is only read when flush_flag 4 / flush3 can run (:704-716): N_active > 2 and melt water present
   const bool flush_possible = ((CFG(flush_flag) == 5 || (K::general && (CFG(flush_flag) == 4 || CFG(flush_flag) == 6))) && Na > 2 &&
                                CL(melt_thick) + CL(melt_thick_snow) > 0.000000000001);
@@ -3220,7 +3268,7 @@ __device__ __forceinline__ void column_step(Col &c, Ctx &x, long long col, doubl
         if (CL(melt_thick_snow) > 0.0) GS(FREEBOARD) = func_freeboard<K>(c, x);  // layer 1 changed since the last evaluation (:717)
         ST_COUNT(CT_L_FLUSH3, (unsigned long long)__popcll(__ballot(1)));
         flush3<K>(c, x);
-        c.flags |= COLF_DIRTY;
+        c.flags |= COLF_DIRTY | COLF_FLUSHED;
         if (c.status) return;
       }
     }

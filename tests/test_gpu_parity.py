@@ -350,6 +350,38 @@ def test_full_size_cfg3_million_columns_properties():
     assert_state_close(g.get_state(0, 64), o.get_state(), what="cfg3 columns 0..63")
 
 
+def test_headline_workload_at_full_size_against_the_oracle():
+    """The configuration bench.py times, as bench.py builds it (its own `workload` / `upload_tiled`): 1 048 576 columns x 80 layers
+    (20 + 40 + 20), the 256-member spun-up SHEBA ensemble tiled over the columns, one bench step of 500 time steps with the two
+    concurrent launches of a large handle.  Every member against the oracle (256 columns x 500 steps on the CPU), and the copies of
+    a member bitwise equal wherever they ran -- first, middle and last block of the handle, both launch halves."""
+    import argparse
+    import bench
+    a = argparse.Namespace(workload="sheba", nlayer=80)
+    cfg, st, pert, clock, forcing, _, _ = bench.workload(a)
+    ncol, nmem, nsteps = 1 << 20, st.ncol, 500
+    assert cfg.nlayer == 80 and nmem == 256
+    g = samsim_amd.hip_solver(cfg, ncol)
+    g.set_forcing(*forcing, bench.tile(pert[0], ncol), bench.tile(pert[1], ncol))
+    bench.upload_tiled(g, st, ncol, 0)
+    g.set_clock(**clock)
+    g.set_output_window(0, 0)
+    g.step(nsteps)
+    assert not g.get_status()[0].any()
+    first = g.get_state(0, nmem)
+    for c0 in (nmem, ncol // 2 - nmem, ncol // 2, ncol - nmem):
+        other = g.get_state(c0, nmem)
+        assert np.array_equal(other.lay, first.lay) and np.array_equal(other.scal, first.scal) and np.array_equal(other.n_active, first.n_active), c0
+    o = oracle_solver(cfg, nmem)
+    o.set_threads(NTHREADS)
+    o.set_forcing(*forcing, pert[0], pert[1])
+    from samsim_amd.capi import State
+    o.set_state(State(st.lay, st.scal, st.n_active.astype(np.int32)))
+    o.set_clock(**clock)
+    o.step(nsteps)
+    assert_state_close(first, o.get_state(), what="headline workload, members 0..255")
+
+
 def _ensemble(nlayer, n):
     """first n members of the spun-up perturbed SHEBA ensemble fixture (prognostic arrays only)"""
     from samsim_amd.capi import State

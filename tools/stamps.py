@@ -20,7 +20,8 @@ NAMES = ["t_prologue", "t_down_fused", "t_down_unfused", "t_surface", "t_up", "t
          "wave_steps", "fused", "unfused", "up_trips", "newton_wave", "newton_lane", "lanes", "down_trips", "drain_wave",
          "drain_lane", "dirty", "lanes_coupling", "t_up_head", "t_up_getT", "t_up_tail", "t_down_A", "t_down_BC",
          "lanes_flood_possible", "lanes_irregular", "lanes_dirty", "lanes_unfused", "lanes_flush3", "lanes_regrid", "lanes_freeboard",
-         "lanes_refill_psi", "down_rows_interior", "down_rows_without_expulsion"] + [f"slot{i}" for i in range(35, 48)]
+         "lanes_refill_psi", "down_rows_interior", "down_rows_without_expulsion", "getT_lanes_redone_by_the_general_routine",
+         "getT_waves_with_such_a_lane", "their_evaluations_wave_max", "up_sweeps_without_the_next_first_sweep"] + [f"slot{i}" for i in range(39, 48)]
 
 
 def main():
