@@ -1586,6 +1586,17 @@ __device__ RARE void sweep_beer(Col &c, const Ctx &x, double beer0) {
 // the arrays (old temperatures, this step's volume fractions, the thickness flooding may just have changed): the fused down sweep
 // applies it on the fly, so the up sweep never does.  Layer 1 is left to the top-layer block (fl_Q(1) comes from the surface
 // balance); fl_Q(2) and the two energy sums are handed on in the column struct.
+// sub_fl_Q, mo_thermo_functions.f90:201-223, between two layers: dT / (thick_a/(2 k_a) + thick_b/(2 k_b)).  With the half-layer
+// conductance g = 2k/thick = 2k * (1/thick) -- 1/thick is at hand in the sweeps, one value per stretch of the grid -- the flux is
+// dT * g_a*g_b / (g_a + g_b): one division per layer where the resistance form has two (a division is a quarter-rate reciprocal
+// plus five instructions).  An ulp-level re-association like the shared reciprocals; both orders of the step use it.
+__device__ __forceinline__ double heat_conductance(double psi_s, double psi_l, double rth) {
+  return (2.0 * (psi_s * k_s + psi_l * k_l)) * rth;
+}
+__device__ __forceinline__ double heat_flux_between(double dT, double g_a, double g_b) {
+  return quot(dT * (g_a * g_b), g_a + g_b);
+}
+
 template <class K>
 __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
   const int Na = c.Na, N = c.N;
@@ -1595,7 +1606,7 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
   c.flq2 = 0.0;
   if (Na >= 2) {
     double T_up = LAY(SAMSIM_A_T, 1);
-    double hr_up = LAY(SAMSIM_A_THICK, 1) / (2.0 * (LAY(SAMSIM_A_PSI_S, 1) * k_s + LAY(SAMSIM_A_PSI_L, 1) * k_l));
+    double g_up = heat_conductance(LAY(SAMSIM_A_PSI_S, 1), LAY(SAMSIM_A_PSI_L, 1), recip(LAY(SAMSIM_A_THICK, 1)));
     double flq_k = 0.0;   // fl_Q(k)
     constexpr int CH = RARE_CHUNK / 2;   // five operands per layer (rows requested a chunk at a time, see RARE_CHUNK)
     THICK_RULE_INIT(tr);
@@ -1613,8 +1624,8 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
         const int k = k0 + i;
         if (k <= Na) {
           const double T = T_[i];
-          const double hr = th_[i] / (2.0 * (ps_[i] * k_s + pl_[i] * k_l));
-          const double flq = (T - T_up) / (hr_up + hr);
+          const double gk = heat_conductance(ps_[i], pl_[i], recip(th_[i]));
+          const double flq = heat_flux_between(T - T_up, g_up, gk);
           if (k == 2) c.flq2 = flq;
           if (k >= 3) {   // layer k-1: both of its fluxes are known now
             const double H_b = Hm_[i];
@@ -1623,7 +1634,7 @@ __device__ RARE void sweep_heat_down(Col &c, const Ctx &x) {
             esum += H_b - H_abs;
             LAY(SAMSIM_A_H_ABS, k - 1) = H_abs;
           }
-          T_up = T; hr_up = hr; flq_k = flq;
+          T_up = T; g_up = gk; flq_k = flq;
         }
       }
     }
@@ -1670,7 +1681,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
   int stop_layer = 0;
   bool store_psi = true;                 // layers 1 and 2 always; the others as decided after layer 2 (below)
   // conductive heat fluxes (sub_heat_fluxes, mo_heat_fluxes.f90:272-285): see C(j-1) below
-  double hr_up = 0.0, flq_up = 0.0;      // half resistance thick/(2k) of layer j-1, fl_Q(j-1)
+  double g_up = 0.0, flq_up = 0.0;       // half-layer conductance 2k/thick of layer j-1, fl_Q(j-1)
   double esum = 0.0;                     // SUM(H_abs before - after) of the conductive update, for the energy assert
 
   // The sweeps are latency bound (a wave waits on memory for most of its life), so the loads run ahead of the arithmetic:
@@ -1758,12 +1769,13 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       LAYU(SAMSIM_A_PSI_G, j) = psi_g;
     }
     // sub_fl_Q (mo_thermo_functions.f90:201-223): fl_Q(j) = (T(j) - T(j-1)) / (thick(j-1)/(2k(j-1)) + thick(j)/(2k(j))) with the
-    // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op);
+    // temperatures and volume fractions of the first sweep, k = psi_s*k_s + psi_l*k_l (the reference adds psi_g*0._wp: a no-op),
+    // evaluated through the half-layer conductances (heat_flux_between);
     // th_l: the thickness the conduction and the drainage see (flooding changes layer 1's after the expulsion)
     const bool flooded_here = FIRST && (c.flags & COLF_FLOODED) != 0;
     const double th_l = flooded_here ? LAYU(SAMSIM_A_THICK, 1) : thick;
-    const double hr = quot(th_l, 2.0 * (ex.psi_s * k_s + ex.psi_l * k_l));
-    const double flq = (j >= 2) ? quot(T - prev.T, hr_up + hr) : 0.0;
+    const double gj = heat_conductance(ex.psi_s, ex.psi_l, flooded_here ? recip(th_l) : rth);
+    const double flq = (j >= 2) ? heat_flux_between(T - prev.T, g_up, gj) : 0.0;
     if (j == 2) c.flq2 = flq;
     m = m + flm_next - flm_j;
     if (flm_next < 0.0) {
@@ -1880,7 +1892,7 @@ __device__ __forceinline__ void sweep_down_fused(Col &c, const Ctx &x, bool stor
       minS = dmin(minS, prev.S_abs);
       flup_pp = prev.flup;
     }
-    hr_up = hr; flq_up = flq;
+    g_up = gj; flq_up = flq;
     prev.T = Tl; prev.SA = SA; prev.mA = mA; prev.S_abs = S_abs; prev.H_abs = H_abs; prev.m = m; prev.flup = flup; prev.ch = ch;
     if (!LAST && !FIRST) { ISA_MARK("D_LAYER_END"); }
     ST_MARK(ST_D_B);
