@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """the two tests that wait for the background free runs (tests/background_runs.py) go last: the runs then have the whole session
+    beside them, and the session does not sit waiting for them in the middle"""
+    waits = ("test_sheba_free_run_from_open_water_against_the_reference_records",
+             "test_the_five_later_era_sites_free_run_against_the_reference_records")
+    last = [i for i in items if i.name in waits]
+    if last:
+        items[:] = [i for i in items if i.name not in waits] + last
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from tests.oracle_lib import load_oracle
