@@ -23,7 +23,11 @@ __device__ __forceinline__ size_t idx(size_t ncol, size_t col, int a, int k) {
   return ((size_t)a * NL + k) * ncol + col;
 }
 
-template <int LAYOUT>
+// NT: the loads carry the non-temporal hint, as the product's sweeps do
+template <bool NT>
+__device__ __forceinline__ double ld(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <int LAYOUT, bool NT = false>
 __global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t ncol, int steps, int work) {
   extern __shared__ double pad[];          // sized so that 16 blocks fit a CU: 4 waves / SIMD
   const size_t col = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -31,8 +35,8 @@ __global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t n
   double carry = 0.0;
   for (int s = 0; s < steps; ++s) {
     for (int k = 0; k < NL; ++k) {                       // down sweep
-      double v = carry + lay[idx<LAYOUT>(ncol, col, T, k)] + lay[idx<LAYOUT>(ncol, col, S, k)] + lay[idx<LAYOUT>(ncol, col, M, k)] +
-                 lay[idx<LAYOUT>(ncol, col, H, k)];
+      double v = carry + ld<NT>(lay + idx<LAYOUT>(ncol, col, T, k)) + ld<NT>(lay + idx<LAYOUT>(ncol, col, S, k)) + ld<NT>(lay + idx<LAYOUT>(ncol, col, M, k)) +
+                 ld<NT>(lay + idx<LAYOUT>(ncol, col, H, k));
       for (int i = 0; i < work; ++i) v = v * 1.0000001 + 1e-9;
       lay[idx<LAYOUT>(ncol, col, M, k)] = v + 1.0;
       lay[idx<LAYOUT>(ncol, col, S, k)] = v + 2.0;
@@ -40,7 +44,7 @@ __global__ void __launch_bounds__(64, 4) walk(double *__restrict__ lay, size_t n
       carry = v * 1e-3;
     }
     for (int k = NL - 1; k >= 0; --k) {                  // up sweep
-      double v = carry + lay[idx<LAYOUT>(ncol, col, H, k)] + lay[idx<LAYOUT>(ncol, col, M, k)] + lay[idx<LAYOUT>(ncol, col, S, k)];
+      double v = carry + ld<NT>(lay + idx<LAYOUT>(ncol, col, H, k)) + ld<NT>(lay + idx<LAYOUT>(ncol, col, M, k)) + ld<NT>(lay + idx<LAYOUT>(ncol, col, S, k));
       for (int i = 0; i < 2 * work; ++i) v = v * 1.0000001 + 1e-9;
       lay[idx<LAYOUT>(ncol, col, T, k)] = v * 1e-6;
       carry = v * 1e-3;
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(64, 4) walk_pairs(double2 *__restrict__ lay, s
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int LAYOUT>
+template <int LAYOUT, bool NT = false>
 int run(double *lay, size_t ncol, int steps, int work, const char *name) {
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -92,7 +96,7 @@ int run(double *lay, size_t ncol, int steps, int work, const char *name) {
   for (int rep = 0; rep < 3; ++rep) {
     float ms;
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(walk<LAYOUT>, dim3(ncol / 64), dim3(64), 10000, 0, lay, ncol, steps, work);
+    hipLaunchKernelGGL((walk<LAYOUT, NT>), dim3(ncol / 64), dim3(64), 10000, 0, lay, ncol, steps, work);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
   }
@@ -109,6 +113,7 @@ int main(int argc, char **argv) {
   for (int a = 1; a < (argc > 1 ? argc : 2); ++a) {
     const int work = argc > 1 ? atoi(argv[a]) : 24;
     if (run<0>(lay, ncol, steps, work, "[block][layer][array][lane], T behind thick (the product)")) return 1;
+    if (run<0, true>(lay, ncol, steps, work, "the same with non-temporal loads (the product's sweeps)")) return 1;
     if (run<1>(lay, ncol, steps, work, "[block][layer][array][lane], H_abs S_abs m T contiguous")) return 1;
     if (run<2>(lay, ncol, steps, work, "[block][array][layer][lane]")) return 1;
     if (run<3>(lay, ncol, steps, work, "[array][layer][column]")) return 1;
