@@ -237,9 +237,23 @@ def lib_md5():
         return hashlib.md5(f.read()).hexdigest()
 
 
+def source_md5():
+    """md5 over the sources the library is built from (samsim_amd/csrc/*.hip|*.h|*.cpp|Makefile + include/samsim.h), in name order"""
+    import glob
+    h = hashlib.md5()
+    files = sorted(glob.glob(os.path.join(ROOT, "samsim_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "samsim_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "samsim_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "samsim_amd", "csrc", "Makefile"),
+                                                                                      os.path.join(ROOT, "include", "samsim.h")])
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def profiled_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-    correction applied): only quoted when the profiled library is the one loaded now"""
+    correction applied): only quoted when the profiled library is the one loaded now -- the same binary, or (a rebuild changes the
+    binary's md5 with its path) the default library built from the very sources the profiled one was built from"""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
@@ -248,9 +262,11 @@ def profiled_traffic(key):
     e = t.get(key)
     if not isinstance(e, dict):
         return None, f"no PMC profile committed for {key}"
-    if e.get("lib_md5") != lib_md5():
-        return None, f"PMC profile {e.get('source')} was taken on another build of the library (md5 differs): not quoted"
-    return e.get("bytes_per_launch"), f"static: {e.get('source')} (same library build, md5 {e.get('lib_md5')[:12]})"
+    if e.get("lib_md5") == lib_md5():
+        return e.get("bytes_per_launch"), f"static: {e.get('source')} (same library build, md5 {e.get('lib_md5')[:12]})"
+    if "SAMSIM_HIP_LIB" not in os.environ and e.get("src_md5") and e.get("src_md5") == source_md5():
+        return e.get("bytes_per_launch"), f"static: {e.get('source')} (library rebuilt from the profiled sources, source md5 {e.get('src_md5')[:12]})"
+    return None, f"PMC profile {e.get('source')} was taken on another build of the library (md5 differs): not quoted"
 
 
 def spawn_ranks(args):

@@ -36,7 +36,10 @@ for f in glob.glob(os.path.join(src, "prof500/trace/*/*_kernel_trace.csv")):
             if i == 0 or "samsim_step_kernel" in line:
                 out.write(line)
 d = json.load(open(os.path.join(src, "pmc_summary_500.json")))
-t = {"sheba:1048576:80:500": {"bytes_per_launch": d["hbm_bytes_per_launch"], "lib_md5": d["lib_md5"],
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+# (src_md5: the sources in the tree NOW -- run this right after the profiling call, before the sources change)
+t = {"sheba:1048576:80:500": {"bytes_per_launch": d["hbm_bytes_per_launch"], "lib_md5": d["lib_md5"], "src_md5": bench.source_md5(),
                                 "source": f"profiles/{rnd}_pmc_summary_substeps500.json",
                                 "note": "per step of 500 time steps = the two launches of the step added (2*FETCH_SIZE + WRITE_SIZE)*1024"}}
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
